@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU ORACLE (oracle/stfem_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product (dealii-stfem_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libstfem_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "stfem_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libstfem_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.stfo_create.restype = C.c_void_p
+        L.stfo_create.argtypes = [C.c_int, C.POINTER(C.c_int), _dp, C.c_int]
+        L.stfo_destroy.argtypes = [C.c_void_p]
+        L.stfo_n_dofs.restype = C.c_long
+        L.stfo_n_dofs.argtypes = [C.c_void_p]
+        L.stfo_n_cells.restype = C.c_long
+        L.stfo_n_cells.argtypes = [C.c_void_p]
+        L.stfo_n_q.argtypes = [C.c_void_p]
+        L.stfo_set_threads.argtypes = [C.c_int]
+        L.stfo_set_coefficient.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.stfo_quadrature_points.argtypes = [C.c_void_p, _dp]
+        L.stfo_coefficient_values.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                              C.c_double, C.POINTER(C.c_int), _dp, _dp, _dp]
+        L.stfo_space_vmult.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp, _dp]
+        L.stfo_st_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int,
+                                    C.POINTER(_dp), C.POINTER(_dp)]
+        L.stfo_diagonal.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp]
+        L.stfo_dense.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp]
+        L.stfo_gauss.argtypes = [C.c_int, _dp, _dp]
+        L.stfo_gauss_lobatto.argtypes = [C.c_int, _dp]
+        L.stfo_gauss_radau_right.argtypes = [C.c_int, _dp]
+        L.stfo_shape_tables.argtypes = [C.c_int, C.c_int, _dp, _dp]
+        L.stfo_cg_weights.argtypes = [C.c_int, _dp, _dp]
+        L.stfo_dg_weights.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.stfo_time_weights.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]
+        L.stfo_time_weights_wave.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int,
+                                             _dp, _dp, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def gauss(n):
+    x = np.zeros(n); w = np.zeros(n)
+    lib().stfo_gauss(n, _p(x), _p(w))
+    return x, w
+
+
+def gauss_lobatto(n):
+    x = np.zeros(n)
+    lib().stfo_gauss_lobatto(n, _p(x))
+    return x
+
+
+def gauss_radau_right(n):
+    x = np.zeros(n)
+    lib().stfo_gauss_radau_right(n, _p(x))
+    return x
+
+
+def shape_tables(p, nq=None):
+    nq = nq or p + 1
+    S = np.zeros((nq, p + 1)); D = np.zeros((nq, p + 1))
+    lib().stfo_shape_tables(p, nq, _p(S), _p(D))
+    return S, D
+
+
+CGP, DG = 0, 1
+
+
+def cg_weights(r):
+    M = np.zeros((r, r + 1)); D = np.zeros((r, r + 1))
+    assert lib().stfo_cg_weights(r, _p(M), _p(D)) == 0
+    return M, D
+
+
+def dg_weights(r):
+    M = np.zeros((r + 1, r + 1)); D = np.zeros((r + 1, r + 1)); j = np.zeros((r + 1, 1))
+    assert lib().stfo_dg_weights(r, _p(M), _p(D), _p(j)) == 0
+    return M, D, j
+
+
+def time_weights(ttype, r, tau=1.0, nsteps=1):
+    nb = (r if ttype == CGP else r + 1) * nsteps
+    A = np.zeros((nb, nb)); B = np.zeros((nb, nb)); G = np.zeros((nb, 1)); Z = np.zeros((nb, 1))
+    assert lib().stfo_time_weights(ttype, r, tau, nsteps, _p(A), _p(B), _p(G), _p(Z)) == nb
+    return A, B, G, Z
+
+
+def time_weights_wave(ttype, r, tau=1.0, nsteps=1):
+    nb = (r if ttype == CGP else r + 1) * nsteps
+    A = np.zeros((nb, nb)); B = np.zeros((nb, nb))
+    v = [np.zeros((nb, 1)) for _ in range(3)]
+    assert lib().stfo_time_weights_wave(ttype, r, tau, nsteps, _p(A), _p(B),
+                                        _p(v[0]), _p(v[1]), _p(v[2])) == nb
+    return A, B, v[0], v[1], v[2]
+
+
+class Oracle:
+    """CPU restatement of MatrixFreeOperator + SystemMatrix on a structured hex mesh."""
+
+    def __init__(self, p, ncell, vertices, dirichlet_mask=63):
+        self.p = p
+        self.ncell = tuple(int(v) for v in ncell)
+        nc = (C.c_int * 3)(*self.ncell)
+        v = np.ascontiguousarray(vertices, dtype=np.float64)
+        assert v.size == 3 * np.prod([n + 1 for n in self.ncell])
+        self._h = lib().stfo_create(p, nc, _p(v), dirichlet_mask)
+        assert self._h
+        self.n_dofs = lib().stfo_n_dofs(self._h)
+        self.n_cells = lib().stfo_n_cells(self._h)
+        self.nq = lib().stfo_n_q(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().stfo_destroy(self._h)
+            self._h = None
+
+    def set_coefficient(self, which, coef):
+        if coef is None:
+            lib().stfo_set_coefficient(self._h, which, None)
+        else:
+            c = np.ascontiguousarray(coef, dtype=np.float64)
+            assert c.size == self.n_cells * self.nq ** 3
+            lib().stfo_set_coefficient(self._h, which, _p(c))
+
+    def quadrature_points(self):
+        out = np.zeros((self.n_cells, self.nq ** 3, 3))
+        lib().stfo_quadrature_points(self._h, _p(out))
+        return out
+
+    def coefficient_values(self, c1=1.0, c2=9.0, c3=16.0, distort=0.0, subdivisions=(1, 1, 1),
+                           lower=(0, 0, 0), upper=(1, 1, 1)):
+        out = np.zeros((self.n_cells, self.nq ** 3))
+        sub = (C.c_int * 3)(*subdivisions)
+        lo = np.array(lower, dtype=np.float64); up = np.array(upper, dtype=np.float64)
+        lib().stfo_coefficient_values(self._h, c1, c2, c3, distort, sub, _p(lo), _p(up), _p(out))
+        return out
+
+    def space_vmult(self, src, mass=0.0, laplace=0.0):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        dst = np.zeros(self.n_dofs)
+        lib().stfo_space_vmult(self._h, mass, laplace, _p(dst), _p(src))
+        return dst
+
+    def st_vmult(self, alpha, beta, src, transpose=False, dst=None):
+        """src: (n_src_blocks, n_dofs). Returns (n_dst_blocks, n_dofs); adds into dst if given."""
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        nrows, ncols = alpha.shape
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        nsrc, ndst = (nrows, ncols) if transpose else (ncols, nrows)
+        assert src.shape == (nsrc, self.n_dofs)
+        add = dst is not None
+        out = np.ascontiguousarray(dst, dtype=np.float64).copy() if add else \
+            np.zeros((ndst, self.n_dofs))
+        sp = (_dp * nsrc)(*[_p(src[i]) for i in range(nsrc)])
+        dp = (_dp * ndst)(*[_p(out[i]) for i in range(ndst)])
+        lib().stfo_st_vmult(self._h, nrows, ncols, _p(alpha), _p(beta), int(transpose), int(add),
+                            dp, sp)
+        return out
+
+    def diagonal(self, mass=0.0, laplace=0.0):
+        d = np.zeros(self.n_dofs)
+        lib().stfo_diagonal(self._h, mass, laplace, _p(d))
+        return d
+
+    def dense(self, mass=0.0, laplace=0.0):
+        A = np.zeros((self.n_dofs, self.n_dofs))
+        lib().stfo_dense(self._h, mass, laplace, _p(A))
+        return A

@@ -1,0 +1,86 @@
+/*
+ * stfem_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's matrix-free space-time operator
+ * apply.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may call it.  The product path (dealii-stfem_amd/csrc) never links it.
+ *
+ * Parity status: the vmult result itself is "parity unpinned" by the reference
+ * (it ships no golden vmult vector and deal.II, which holds the arithmetic, is
+ * absent from /root/reference and from this image).  What IS pinned:
+ *   - the temporal matrices against the reference's tests/tp_02.output,
+ *   - K/M against an independent numpy dense assembly (tests/golden/),
+ *   - the reference's own method of tests/tp_05dgp_support.cc:132-151
+ *     (matrix-free apply == assembled matrix apply per unit vector).
+ *
+ * Reference files restated (paths relative to /root/reference):
+ *   include/operators.h:536-611   SystemMatrix::vmult/Tvmult/vmult_slice_add
+ *   include/operators.h:1013-1018 MatrixFreeOperator::vmult (cell_loop, dst zeroed)
+ *   include/operators.h:1112-1173 do_cell_integral_range / do_cell_integral_local
+ *   include/operators.h:1060-1087 evaluate_coefficient (coefficient REPLACES scaling)
+ *   include/operators.h:870-965   Coefficient
+ *   include/operators.h:1092-1110 compute_diagonal
+ *   include/fe_time.h:351-409, 485-514, 643-744, 157-305; fe_time.cc:152-169
+ * deal.II semantics restated from its documentation: FE_Q(p) on Gauss-Lobatto
+ * nodes, lexicographic tensor ordering, QGauss(p+1) on [0,1], MappingQ1,
+ * homogeneous constraints (read as 0, never written).
+ */
+#ifndef STFEM_ORACLE_H
+#define STFEM_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct stfo_ctx stfo_ctx;
+
+/* 1D rules on [0,1] */
+void stfo_gauss(int n, double *x, double *w);
+void stfo_gauss_lobatto(int n, double *x);
+void stfo_gauss_radau_right(int n, double *x);
+/* S[q*(p+1)+a] = l_a(x_q), D[q*(p+1)+a] = l_a'(x_q); nodes GLL(p+1), x_q Gauss(nq) */
+void stfo_shape_tables(int p, int nq, double *S, double *D);
+
+/* vertices: (ncell[0]+1)*(ncell[1]+1)*(ncell[2]+1)*3 doubles, x fastest, xyz interleaved.
+ * dirichlet_mask: bit0 -x, bit1 +x, bit2 -y, bit3 +y, bit4 -z, bit5 +z. */
+stfo_ctx *stfo_create(int p, const int ncell[3], const double *vertices, int dirichlet_mask);
+void stfo_destroy(stfo_ctx *);
+long stfo_n_dofs(const stfo_ctx *);
+long stfo_n_cells(const stfo_ctx *);
+int stfo_n_q(const stfo_ctx *);
+void stfo_set_threads(int n);
+
+/* which: 0 = mass coefficient, 1 = laplace coefficient; coef[cell*nq^3+q] or NULL to clear */
+void stfo_set_coefficient(stfo_ctx *, int which, const double *coef);
+/* physical coordinates of all quadrature points: out[(cell*nq^3+q)*3 + d] */
+void stfo_quadrature_points(const stfo_ctx *, double *out);
+/* operators.h:870-965: c(x,y) piecewise constant, optional per-coarse-cell random factor */
+void stfo_coefficient_values(const stfo_ctx *, double c1, double c2, double c3, double distort,
+                             const int subdivisions[3], const double lower[3],
+                             const double upper[3], double *out);
+
+/* dst = (mass_scaling*M_c + laplace_scaling*K_c) src ; operators.h:1013-1018,1112-1173 */
+void stfo_space_vmult(const stfo_ctx *, double mass_scaling, double laplace_scaling, double *dst,
+                      const double *src);
+/* reference-structured space-time apply, operators.h:536-611.
+ * alpha,beta: row-major nrows x ncols.  transpose: index Alpha(i,j) (Tvmult).
+ * add==0 zeroes dst first.  K = MatrixFreeOperator(0,1), M = (1,0). */
+void stfo_st_vmult(const stfo_ctx *, int nrows, int ncols, const double *alpha, const double *beta,
+                   int transpose, int add, double *const *dst, const double *const *src);
+void stfo_diagonal(const stfo_ctx *, double mass_scaling, double laplace_scaling, double *diag);
+/* dense n x n row-major by the unit-vector method (tp_05dgp_support.cc:140-149) */
+void stfo_dense(const stfo_ctx *, double mass_scaling, double laplace_scaling, double *A);
+
+/* temporal matrices. type: 0 = CGP, 1 = DG.  Row-major, nb = nt*nsteps. Returns nb. */
+int stfo_time_nb(int type, int r, int nsteps);
+int stfo_cg_weights(int r, double *M /* r x (r+1) */, double *Dm /* r x (r+1) */);
+int stfo_dg_weights(int r, double *M, double *Dm, double *jump);
+int stfo_time_weights(int type, int r, double tau, int nsteps, double *Alpha, double *Beta,
+                      double *Gamma, double *Zeta);
+int stfo_time_weights_wave(int type, int r, double tau, int nsteps, double *Alpha_lhs,
+                           double *Beta_lhs, double *rhs_uK, double *rhs_uM, double *rhs_vM);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
