@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: space-time DoF/s of one matrix-free vmult (3D heat, Q4 x cG(2)).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one SystemMatrix::vmult (reference include/operators.h:536-559) of the all-at-once
+space-time system  dst = (Alpha (x) K + Beta (x) M) src  on synthetic data resident in HBM.
+N = 1: BASELINE.json configs[1] (72^3 cells, Q4, cG(2) -> 2 blocks, 48 275 138 space-time DoFs).
+N > 1: weak scaling - every rank owns a 72 x 72 x 72-cell z-slab of a 72 x 72 x 72N mesh (N = 8
+has exactly the cell and DoF count of configs[2]); one packed interface-plane exchange per vmult
+over RCCL send/recv, no other collective on the data path.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(stfem, degree, r, sample_cells, threads):
+    """CPU restatement of the reference algorithm (oracle, kind "port") on a bounded sample of
+    the same workload: same element, same temporal matrices, a smaller cube of cells."""
+    import numpy as np
+    from oracle import oracle
+    oracle.lib().stfo_set_threads(threads)
+    nc = (sample_cells,) * 3
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, r, 1.0 / 144, 1)
+    verts = stfem.mesh_vertices(nc)
+    orc = oracle.Oracle(degree, nc, verts, 63)
+    nb = Alpha.shape[0]
+    X = np.stack([np.random.default_rng(1234 + b).uniform(-1, 1, orc.n_dofs) for b in range(nb)])
+    orc.st_vmult(Alpha, Beta, X)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.st_vmult(Alpha, Beta, X)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    dofs = nb * orc.n_dofs
+    return {"value": dofs * reps / el, "unit": "space-time DoF/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{reps} vmults of Q{degree} x cG({r}) on {sample_cells}^3 cells "
+                      f"({dofs} space-time DoFs), oracle/stfem_oracle.c (2*nb cell loops + axpys, "
+                      f"OpenMP over 8 cell colours); deal.II unavailable, so not the reference binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cells", type=int, default=72, help="cells per direction per GPU")
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--time-degree", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    stfem = importlib.import_module("dealii-stfem_amd")
+    stfem.lib()
+    from importlib import import_module
+    dmod = import_module("dealii-stfem_amd.distributed")
+
+    p, r, n = args.degree, args.time_degree, args.cells
+    global_nc = (n, n, n * world)
+    slab = dmod.make_slab(global_nc, rank, world)
+    # tests/tp_01.cc:106-109 with 9 subdivisions, refinement 3: tau = 1/144
+    tau = 1.0 / 144
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, r, tau, 1)
+    nb = Alpha.shape[0]
+    ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=(0, 0, float(slab.z0) / n),
+                                   upper=(1, 1, float(slab.z1) / n),
+                                   dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    ndofs = ctx.n_dofs
+    nx = p * n + 1
+    plane = nx * nx
+
+    # synthetic data, resident in HBM before the timed region (torch = device-memory plumbing)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    src_t = torch.rand((nb, ndofs), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    dst_t = torch.zeros((nb, ndofs), dtype=torch.float64, device=dev)
+    src = stfem.BlockVector(ctx, device_ptrs=[src_t[b].data_ptr() for b in range(nb)])
+    dst = stfem.BlockVector(ctx, device_ptrs=[dst_t[b].data_ptr() for b in range(nb)])
+    bufs = {k: torch.zeros(nb * plane, dtype=torch.float64, device=dev) for k in ("ts", "bs", "tr", "br")}
+    L = stfem.lib()
+    nz_local = p * (slab.z1 - slab.z0) + 1
+
+    def stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def pack(iz, buf):
+        rc = L.stfem_plane_pack(ctx._h, dst._h, iz % nz_local, buf.data_ptr(), stream())
+        assert rc == 0, rc
+
+    def unpack_add(iz, buf):
+        rc = L.stfem_plane_unpack(ctx._h, dst._h, iz % nz_local, buf.data_ptr(), 1, stream())
+        assert rc == 0, rc
+
+    if world > 1:  # make the src ghost plane consistent with its owner once (update_ghost_values)
+        if slab.has_lower:
+            dist.send(src_t[:, :plane].contiguous(), rank - 1)
+        if slab.has_upper:
+            g = torch.empty((nb, plane), dtype=torch.float64, device=dev)
+            dist.recv(g, rank + 1)
+            src_t[:, -plane:] = g
+
+    kernel_ms = []
+
+    def step(record=False):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        A.vmult(dst, src, stream=stream())
+        if record:
+            e1.record()
+            kernel_ms.append((e0, e1))
+        if world > 1:
+            dmod.sharded_vmult(slab, lambda: None, pack, unpack_add, bufs, dist)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # units: owned space-time DoFs of all ranks (interface planes counted once)
+    own = slab.n_owned_planes(p) * plane * nb
+    if world > 1:
+        t = torch.tensor([own], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        total_dofs = int(t.item())
+    else:
+        total_dofs = own
+    ms_per_step = 1e3 * elapsed / args.steps
+    kms = sum(a.elapsed_time(b) for a, b in kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        # 16 B per space-time DoF per vmult (8 B src read + 8 B dst write)
+        alg_bytes = 16.0 * nb * ndofs
+        achieved = alg_bytes / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s",
+            "value": total_dofs * args.steps / elapsed,
+            "unit": "space-time DoF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D heat, Q{p} x cG({r}), {n}x{n}x{n * world} cells Cartesian unit-"
+                                   f"spacing slab mesh, {total_dofs} space-time DoFs"
+                                   + (" = BASELINE configs[1]" if (world, n, p, r) == (1, 72, 4, 2) else ""),
+                       "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
+                       "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(stfem, p, r, args.cpu_sample_cells,
+                                               min(os.cpu_count() or 1, 16))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

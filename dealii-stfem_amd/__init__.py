@@ -1,0 +1,323 @@
+"""dealii-stfem_amd: MI355X-native matrix-free space-time operator apply.
+
+Python is only a thin ctypes veneer over the C-ABI in include/stfem.h (libstfem_hip.so, built
+from csrc/ by `make -C dealii-stfem_amd/csrc`).  The classes keep the reference's names
+(`MatrixFreeOperator`, `SystemMatrix`, include/operators.h:967-1191, 517-663) so tests and
+bench.py read like the reference's callers.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is present, construction raises.
+
+Import with  importlib.import_module("dealii-stfem_amd")  (the hyphen is the package name the
+build contract prescribes).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstfem_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stfem.h")
+
+CGP, DG = 0, 1
+
+
+class StfemError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = lib().stfem_strerror(status).decode()
+        hip = lib().stfem_last_hip_error().decode()
+        super().__init__(f"{what}: {msg} ({status})" + (f" [{hip}]" if hip else ""))
+
+
+def build(force=False):
+    """Compile libstfem_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class _MeshDesc(C.Structure):
+    _fields_ = [("ncell", C.c_int32 * 3), ("vertices", C.POINTER(C.c_double)),
+                ("lower", C.c_double * 3), ("upper", C.c_double * 3),
+                ("dirichlet_mask", C.c_int32), ("device", C.c_int32)]
+
+
+class _SpaceDesc(C.Structure):
+    _fields_ = [("degree", C.c_int32), ("n_q_points_1d", C.c_int32), ("n_components", C.c_int32)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_lib = None
+
+# every symbol include/stfem.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "stfem_ctx_create": (C.c_int, [C.POINTER(_MeshDesc), C.POINTER(_SpaceDesc), C.POINTER(_vp)]),
+    "stfem_ctx_destroy": (None, [_vp]),
+    "stfem_n_dofs": (C.c_int64, [_vp]),
+    "stfem_n_cells": (C.c_int64, [_vp]),
+    "stfem_is_cartesian": (C.c_int, [_vp]),
+    "stfem_set_coefficient": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "stfem_vector_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "stfem_vector_wrap": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "stfem_vector_destroy": (None, [_vp]),
+    "stfem_vector_n_blocks": (C.c_int, [_vp]),
+    "stfem_vector_block": (_vp, [_vp, C.c_int]),
+    "stfem_vector_upload": (C.c_int, [_vp, C.POINTER(_dp)]),
+    "stfem_vector_download": (C.c_int, [_vp, C.POINTER(_dp)]),
+    "stfem_st_vmult": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "stfem_space_vmult": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp]),
+    "stfem_diagonal": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
+    "stfem_tensorproduct_add": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp]),
+    "stfem_dot": (C.c_int, [_vp, _vp, _vp, C.c_int64, _dp, _vp]),
+    "stfem_plane_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "stfem_plane_unpack": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "stfem_fe_time_weights": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
+    "stfem_fe_time_weights_wave": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int,
+                                             _dp, _dp, _dp, _dp, _dp]),
+    "stfem_mesh_vertices": (C.c_int, [C.POINTER(C.c_int32), _dp, _dp, C.c_double, C.c_uint64,
+                                      C.c_int32, C.c_int32, _dp]),
+    "stfem_coefficient_per_cell": (C.c_int, [C.POINTER(C.c_int32), _dp, C.c_double, C.c_double,
+                                             C.c_double, C.c_double, C.POINTER(C.c_int32), _dp,
+                                             _dp, _dp]),
+    "stfem_strerror": (C.c_char_p, [C.c_int]),
+    "stfem_last_hip_error": (C.c_char_p, []),
+    "stfem_last_kernel_name": (C.c_char_p, [_vp]),
+}
+
+
+def lib():
+    """Loads the HIP library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C dealii-stfem_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _check(status, what):
+    if status != 0:
+        raise StfemError(status, what)
+
+
+# --------------------------------------------------------------------------- host helpers
+
+
+def get_fe_time_weights(ttype, r, time_step_size=1.0, n_timesteps_at_once=1):
+    """fe_time.h:351-409 -> (Alpha, Beta, Gamma, Zeta)."""
+    nb = (r if ttype == CGP else r + 1) * n_timesteps_at_once
+    A = np.zeros((nb, nb)); B = np.zeros((nb, nb)); G = np.zeros((nb, 1)); Z = np.zeros((nb, 1))
+    rc = lib().stfem_fe_time_weights(ttype, r, time_step_size, n_timesteps_at_once,
+                                     _p(A), _p(B), _p(G), _p(Z))
+    if rc != nb:
+        raise StfemError(rc, "stfem_fe_time_weights")
+    return A, B, G, Z
+
+
+def get_fe_time_weights_wave(ttype, r, time_step_size=1.0, n_timesteps_at_once=1):
+    """fe_time.h:157-305 -> (Alpha_lhs, Beta_lhs, rhs_uK, rhs_uM, rhs_vM)."""
+    nb = (r if ttype == CGP else r + 1) * n_timesteps_at_once
+    A = np.zeros((nb, nb)); B = np.zeros((nb, nb))
+    v = [np.zeros((nb, 1)) for _ in range(3)]
+    rc = lib().stfem_fe_time_weights_wave(ttype, r, time_step_size, n_timesteps_at_once,
+                                          _p(A), _p(B), _p(v[0]), _p(v[1]), _p(v[2]))
+    if rc != nb:
+        raise StfemError(rc, "stfem_fe_time_weights_wave")
+    return A, B, v[0], v[1], v[2]
+
+
+def mesh_vertices(global_ncell, lower=(0, 0, 0), upper=(1, 1, 1), distort=0.0, seed=5489,
+                  z_range=None):
+    """Structured vertex grid of a z-slab [z0, z1) of cells of the global mesh."""
+    gn = (C.c_int32 * 3)(*global_ncell)
+    z0, z1 = z_range if z_range else (0, global_ncell[2])
+    lo = np.array(lower, dtype=np.float64); up = np.array(upper, dtype=np.float64)
+    out = np.zeros(((global_ncell[0] + 1) * (global_ncell[1] + 1) * (z1 - z0 + 1), 3))
+    _check(lib().stfem_mesh_vertices(gn, _p(lo), _p(up), distort, seed, z0, z1, _p(out)),
+           "stfem_mesh_vertices")
+    return out
+
+
+def coefficient_per_cell(ncell, vertices, c1=1.0, c2=9.0, c3=16.0, distort_coeff=0.0,
+                         subdivisions=(1, 1, 1), lower=(0, 0, 0), upper=(1, 1, 1)):
+    nc = (C.c_int32 * 3)(*ncell); sub = (C.c_int32 * 3)(*subdivisions)
+    lo = np.array(lower, dtype=np.float64); up = np.array(upper, dtype=np.float64)
+    v = np.ascontiguousarray(vertices, dtype=np.float64)
+    out = np.zeros(int(np.prod(ncell)))
+    _check(lib().stfem_coefficient_per_cell(nc, _p(v), c1, c2, c3, distort_coeff, sub, _p(lo),
+                                            _p(up), _p(out)), "stfem_coefficient_per_cell")
+    return out
+
+
+# --------------------------------------------------------------------------- device objects
+
+
+class BlockVector:
+    """LinearAlgebra::distributed::BlockVector stand-in: n_blocks device arrays (types.h:19-23)."""
+
+    def __init__(self, ctx, n_blocks=None, device_ptrs=None):
+        self.ctx = ctx
+        h = _vp()
+        if device_ptrs is not None:
+            arr = (_vp * len(device_ptrs))(*device_ptrs)
+            _check(lib().stfem_vector_wrap(ctx._h, len(device_ptrs), arr, C.byref(h)),
+                   "stfem_vector_wrap")
+            self.n_blocks = len(device_ptrs)
+        else:
+            _check(lib().stfem_vector_create(ctx._h, n_blocks, C.byref(h)), "stfem_vector_create")
+            self.n_blocks = n_blocks
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.stfem_vector_destroy(self._h)
+            self._h = None
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        assert host.shape == (self.n_blocks, self.ctx.n_dofs)
+        ptrs = (_dp * self.n_blocks)(*[_p(host[b]) for b in range(self.n_blocks)])
+        _check(lib().stfem_vector_upload(self._h, ptrs), "stfem_vector_upload")
+        return self
+
+    def download(self):
+        out = np.zeros((self.n_blocks, self.ctx.n_dofs))
+        ptrs = (_dp * self.n_blocks)(*[_p(out[b]) for b in range(self.n_blocks)])
+        _check(lib().stfem_vector_download(self._h, ptrs), "stfem_vector_download")
+        return out
+
+    def block_ptr(self, b):
+        return lib().stfem_vector_block(self._h, b)
+
+
+class MatrixFreeOperator:
+    """Context = MatrixFree + MatrixFreeOperator state of one rank (operators.h:967-1191)."""
+
+    def __init__(self, degree, ncell, vertices=None, lower=(0, 0, 0), upper=(1, 1, 1),
+                 dirichlet_mask=63, device=0, mass_matrix_scaling=0.0, laplace_matrix_scaling=0.0):
+        self.degree = degree
+        self.ncell = tuple(int(v) for v in ncell)
+        self.mass_matrix_scaling = mass_matrix_scaling
+        self.laplace_matrix_scaling = laplace_matrix_scaling
+        m = _MeshDesc()
+        m.ncell[:] = self.ncell
+        self._verts = None
+        if vertices is not None:
+            self._verts = np.ascontiguousarray(vertices, dtype=np.float64)
+            assert self._verts.size == 3 * np.prod([n + 1 for n in self.ncell])
+            m.vertices = _p(self._verts)
+        m.lower[:] = lower
+        m.upper[:] = upper
+        m.dirichlet_mask = dirichlet_mask
+        m.device = device
+        s = _SpaceDesc(degree, degree + 1, 1)
+        h = _vp()
+        _check(lib().stfem_ctx_create(C.byref(m), C.byref(s), C.byref(h)), "stfem_ctx_create")
+        self._h = h
+        self.n_dofs = lib().stfem_n_dofs(h)
+        self.n_cells = lib().stfem_n_cells(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.stfem_ctx_destroy(self._h)
+            self._h = None
+
+    def m(self):
+        return self.n_dofs
+
+    @property
+    def is_cartesian(self):
+        return bool(lib().stfem_is_cartesian(self._h))
+
+    def evaluate_coefficient(self, values, which=1):
+        """operators.h:1060-1087.  values: None | (n_cells,) | (n_cells, nq^3)."""
+        if values is None:
+            _check(lib().stfem_set_coefficient(self._h, which, 0, None), "stfem_set_coefficient")
+            return
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        layout = 1 if v.size == self.n_cells else 2
+        assert v.size in (self.n_cells, self.n_cells * (self.degree + 1) ** 3)
+        _check(lib().stfem_set_coefficient(self._h, which, layout, _p(v)), "stfem_set_coefficient")
+
+    def initialize_dof_vector(self, n_blocks=1):
+        return BlockVector(self, n_blocks)
+
+    def vmult(self, dst, src, stream=None):
+        _check(lib().stfem_space_vmult(self._h, self.mass_matrix_scaling,
+                                       self.laplace_matrix_scaling, dst._h, src._h, stream),
+               "stfem_space_vmult")
+
+    def compute_diagonal(self, mass=None, laplace=None, stream=None):
+        d = BlockVector(self, 1)
+        _check(lib().stfem_diagonal(self._h,
+                                    self.mass_matrix_scaling if mass is None else mass,
+                                    self.laplace_matrix_scaling if laplace is None else laplace,
+                                    d._h, stream), "stfem_diagonal")
+        return d
+
+    @property
+    def last_kernel_name(self):
+        return lib().stfem_last_kernel_name(self._h).decode()
+
+
+class SystemMatrix:
+    """operators.h:517-663: A = Alpha (x) K + Beta (x) M on one context."""
+
+    def __init__(self, ctx, Alpha, Beta):
+        self.ctx = ctx
+        self.Alpha = np.ascontiguousarray(Alpha, dtype=np.float64)
+        self.Beta = np.ascontiguousarray(Beta, dtype=np.float64)
+        assert self.Alpha.shape == self.Beta.shape and self.Alpha.ndim == 2
+
+    def m(self):
+        return self.Alpha.shape[0] * self.ctx.n_dofs
+
+    def initialize_dof_vector(self):
+        return BlockVector(self.ctx, self.Alpha.shape[0])
+
+    def _apply(self, dst, src, transpose, add, stream):
+        nr, nc = self.Alpha.shape
+        _check(lib().stfem_st_vmult(self.ctx._h, nr, nc, _p(self.Alpha), _p(self.Beta),
+                                    int(transpose), int(add), dst._h, src._h, stream),
+               "stfem_st_vmult")
+
+    def vmult(self, dst, src, stream=None):
+        self._apply(dst, src, False, False, stream)
+
+    def Tvmult(self, dst, src, stream=None):
+        self._apply(dst, src, True, False, stream)
+
+    def vmult_slice(self, dst, src, stream=None):
+        assert self.Alpha.shape[1] == 1
+        self._apply(dst, src, False, False, stream)
+
+    def vmult_slice_add(self, dst, src, stream=None):
+        assert self.Alpha.shape[1] == 1
+        self._apply(dst, src, False, True, stream)
+
+
+def tensorproduct_add(ctx, c, A, b, stream=None):
+    """operators.h:238-250: c_i += A(i,j) b_j, skipping exact zeros."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    _check(lib().stfem_tensorproduct_add(ctx._h, A.shape[0], A.shape[1], _p(A), c._h, b._h,
+                                         stream), "stfem_tensorproduct_add")
+
+
+def dot(ctx, a, b, n_own=0, stream=None):
+    out = C.c_double(0.0)
+    _check(lib().stfem_dot(ctx._h, a._h, b._h, n_own, C.byref(out), stream), "stfem_dot")
+    return out.value

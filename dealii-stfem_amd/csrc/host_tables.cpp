@@ -1,0 +1,547 @@
+// Host-side numerics of the product library (see host_tables.h).
+// Reference semantics restated: include/fe_time.h:157-305, 351-409, 485-514, 643-744;
+// fe_time.cc:152-169; include/operators.h:870-965.  deal.II rules (QGauss, QGaussLobatto,
+// QGaussRadau) are rebuilt from their mathematical definition.
+#include "host_tables.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <random>
+#include <stdexcept>
+
+namespace stfem {
+
+namespace {
+
+// Legendre P_n and P_n' on [-1,1] by the three-term recurrence
+struct LegVal { double p, dp, pm1; };
+LegVal legendre_eval(int n, double x)
+{
+  double a = 1.0, b = x;
+  if (n == 0) return {1.0, 0.0, 0.0};
+  for (int k = 1; k < n; ++k) {
+    const double c = ((2 * k + 1) * x * b - k * a) / (k + 1);
+    a = b;
+    b = c;
+  }
+  const double dp = (std::abs(std::abs(x) - 1.0) < 1e-300) ? 0.0 : n * (x * b - a) / (x * x - 1.0);
+  return {b, dp, a};
+}
+
+// monomial coefficients (ascending) of P_n
+std::vector<double> legendre_monomials(int n)
+{
+  std::vector<double> a{1.0}, b{0.0, 1.0};
+  if (n == 0) return a;
+  for (int k = 1; k < n; ++k) {
+    std::vector<double> c(k + 2, 0.0);
+    for (int i = 0; i <= k; ++i) c[i + 1] += (2.0 * k + 1) / (k + 1) * b[i];
+    for (int i = 0; i < k; ++i) c[i] -= double(k) / (k + 1) * a[i];
+    a = b;
+    b = c;
+  }
+  return b;
+}
+
+// all (real, simple) roots of a polynomial with ascending coefficients: Aberth-Ehrlich
+std::vector<double> real_roots(std::vector<double> c)
+{
+  while (!c.empty() && c.back() == 0.0) c.pop_back();
+  const int n = int(c.size()) - 1;
+  std::vector<std::complex<double>> z(n);
+  for (int i = 0; i < n; ++i) z[i] = std::polar(0.9, 2.0 * M_PI * i / n + 0.4);
+  auto eval = [&](std::complex<double> x, std::complex<double> &d) {
+    std::complex<double> p = c[n];
+    d = 0.0;
+    for (int i = n - 1; i >= 0; --i) {
+      d = d * x + p;
+      p = p * x + c[i];
+    }
+    return p;
+  };
+  for (int it = 0; it < 500; ++it) {
+    double change = 0.0;
+    for (int i = 0; i < n; ++i) {
+      std::complex<double> d, p = eval(z[i], d);
+      std::complex<double> s = 0.0;
+      for (int j = 0; j < n; ++j)
+        if (j != i) s += 1.0 / (z[i] - z[j]);
+      const std::complex<double> w = p / d;
+      const std::complex<double> dz = w / (1.0 - w * s);
+      z[i] -= dz;
+      change = std::max(change, std::abs(dz));
+    }
+    if (change < 1e-15) break;
+  }
+  std::vector<double> r(n);
+  for (int i = 0; i < n; ++i) r[i] = z[i].real();
+  std::sort(r.begin(), r.end());
+  return r;
+}
+
+std::vector<double> poly_deriv(const std::vector<double> &c)
+{
+  std::vector<double> d(c.size() > 1 ? c.size() - 1 : 1, 0.0);
+  for (size_t i = 1; i < c.size(); ++i) d[i - 1] = i * c[i];
+  return d;
+}
+
+template <class F, class DF> double newton_polish(double x, F f, DF df)
+{
+  for (int it = 0; it < 50; ++it) {
+    const double dx = f(x) / df(x);
+    x -= dx;
+    if (std::abs(dx) < 1e-17) break;
+  }
+  return x;
+}
+
+void symmetrise(std::vector<double> &r)
+{
+  const int n = int(r.size());
+  for (int i = 0; i < n / 2; ++i) {
+    const double v = 0.5 * (r[n - 1 - i] - r[i]);
+    r[i] = -v;
+    r[n - 1 - i] = v;
+  }
+  if (n & 1) r[n / 2] = 0.0;
+}
+
+} // namespace
+
+void gauss_rule(int n, std::vector<double> &x, std::vector<double> &w)
+{
+  std::vector<double> r = real_roots(legendre_monomials(n));
+  for (double &v : r)
+    v = newton_polish(
+      v, [&](double t) { return legendre_eval(n, t).p; }, [&](double t) { return legendre_eval(n, t).dp; });
+  symmetrise(r);
+  x.resize(n);
+  w.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const double d = legendre_eval(n, r[i]).dp;
+    x[i] = 0.5 * (r[i] + 1.0);
+    w[i] = 1.0 / ((1.0 - r[i] * r[i]) * d * d);
+  }
+}
+
+std::vector<double> lobatto_points(int n)
+{
+  std::vector<double> x(n);
+  x[0] = 0.0;
+  x[n - 1] = 1.0;
+  if (n > 2) {
+    const int N = n - 1;
+    // interior nodes: roots of P_N'
+    std::vector<double> r = real_roots(poly_deriv(legendre_monomials(N)));
+    for (double &v : r)
+      v = newton_polish(
+        v, [&](double t) { return legendre_eval(N, t).dp; },
+        [&](double t) { // P_N'' from the Legendre ODE
+          const LegVal l = legendre_eval(N, t);
+          return (2.0 * t * l.dp - N * (N + 1.0) * l.p) / (1.0 - t * t);
+        });
+    symmetrise(r);
+    for (int i = 0; i < n - 2; ++i) x[i + 1] = 0.5 * (r[i] + 1.0);
+  }
+  return x;
+}
+
+std::vector<double> radau_right_points(int n)
+{
+  std::vector<double> x(n);
+  x[n - 1] = 1.0;
+  if (n > 1) {
+    // P_n - P_{n-1} has the root +1; deflate it synthetically, then polish on the full form
+    std::vector<double> a = legendre_monomials(n), b = legendre_monomials(n - 1);
+    for (size_t i = 0; i < b.size(); ++i) a[i] -= b[i];
+    std::vector<double> q(n, 0.0); // a(x) = (x-1) q(x)
+    double carry = 0.0;
+    for (int i = n; i >= 1; --i) {
+      q[i - 1] = a[i] + carry;
+      carry = q[i - 1];
+    }
+    std::vector<double> r = real_roots(q);
+    for (double &v : r)
+      v = newton_polish(
+        v, [&](double t) { return legendre_eval(n, t).p - legendre_eval(n - 1, t).p; },
+        [&](double t) { return legendre_eval(n, t).dp - legendre_eval(n - 1, t).dp; });
+    for (int i = 0; i < n - 1; ++i) x[i] = 0.5 * (r[i] + 1.0);
+  }
+  return x;
+}
+
+void lagrange_tables(const std::vector<double> &nodes, const std::vector<double> &x, Mat &V, Mat &G)
+{
+  const int n = int(nodes.size()), m = int(x.size());
+  V.assign(size_t(m) * n, 0.0);
+  G.assign(size_t(m) * n, 0.0);
+  std::vector<double> bw(n, 1.0); // barycentric weights
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b)
+      if (a != b) bw[a] /= (nodes[a] - nodes[b]);
+  for (int q = 0; q < m; ++q)
+    for (int a = 0; a < n; ++a) {
+      double val = bw[a], der = 0.0;
+      for (int b = 0; b < n; ++b)
+        if (b != a) val *= (x[q] - nodes[b]);
+      for (int c = 0; c < n; ++c) {
+        if (c == a) continue;
+        double t = bw[a];
+        for (int b = 0; b < n; ++b)
+          if (b != a && b != c) t *= (x[q] - nodes[b]);
+        der += t;
+      }
+      V[size_t(q) * n + a] = val;
+      G[size_t(q) * n + a] = der;
+    }
+}
+
+void eo_pack(int n, const Mat &X, double *out)
+{
+  const int h = n / 2, m = n / 2;
+  for (int q = 0; q < h; ++q)
+    for (int i = 0; i < h; ++i) {
+      out[q * h + i] = 0.5 * (X[q * n + i] + X[q * n + n - 1 - i]);
+      out[h * h + q * h + i] = 0.5 * (X[q * n + i] - X[q * n + n - 1 - i]);
+    }
+  if (n & 1) {
+    for (int q = 0; q < h; ++q) out[2 * h * h + q] = X[q * n + m];
+    for (int i = 0; i < h; ++i) out[2 * h * h + h + i] = X[m * n + i];
+    out[2 * h * h + 2 * h] = X[m * n + m];
+  }
+}
+
+static Mat transpose(int n, const Mat &A)
+{
+  Mat T(A.size());
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) T[j * n + i] = A[i * n + j];
+  return T;
+}
+
+ShapeTables make_shape_tables(int p)
+{
+  ShapeTables t;
+  const int n = p + 1;
+  t.n = n;
+  t.nodes = lobatto_points(n);
+  gauss_rule(n, t.xq, t.wq);
+  lagrange_tables(t.nodes, t.xq, t.S, t.D);
+  Mat dummy;
+  lagrange_tables(t.xq, t.xq, dummy, t.Dcol);
+  Mat Si(n * n), Dc(n * n);
+  for (int q = 0; q < n; ++q)
+    for (int a = 0; a < n; ++a) {
+      Si[q * n + a] = std::sqrt(t.wq[q]) * t.S[q * n + a];
+      Dc[q * n + a] = std::sqrt(t.wq[q]) * t.Dcol[q * n + a] / std::sqrt(t.wq[a]);
+    }
+  eo_pack(n, Si, t.eo_Si);
+  eo_pack(n, transpose(n, Si), t.eo_SiT);
+  eo_pack(n, Dc, t.eo_Dc);
+  eo_pack(n, transpose(n, Dc), t.eo_DcT);
+  eo_pack(n, t.S, t.eo_S);
+  eo_pack(n, transpose(n, t.S), t.eo_ST);
+  eo_pack(n, t.Dcol, t.eo_Dq);
+  eo_pack(n, transpose(n, t.Dcol), t.eo_DqT);
+  return t;
+}
+
+// --------------------------------------------------------------------------- temporal matrices
+
+int time_nb(int type, int r, int nsteps) { return (type == 0 ? r : r + 1) * nsteps; }
+
+namespace {
+
+struct Step1 {
+  int nt;
+  Mat A, B;               // tau*M_t (lhs part), D_t (lhs part)
+  std::vector<double> t2, t3; // the reference's tmp[2], tmp[3] after the CGP/DG branch
+  std::vector<double> G, Z;   // returned Gamma, Zeta of one step
+};
+
+// get_cg_weights / get_dg_weights + split_lhs_rhs + the branch at fe_time.h:359-371
+Step1 single_step(int type, int r, double tau)
+{
+  Step1 s;
+  std::vector<double> xq, wq;
+  gauss_rule(r + 2, xq, wq);
+  if (type == 0) {
+    if (r < 1) throw std::invalid_argument("cG needs r >= 1");
+    const std::vector<double> trial = lobatto_points(r + 1);
+    const std::vector<double> test(trial.begin() + 1, trial.end());
+    Mat Vt, Gt, Vs, Gs;
+    lagrange_tables(trial, xq, Vt, Gt);
+    lagrange_tables(test, xq, Vs, Gs);
+    s.nt = r;
+    s.A.assign(r * r, 0.0);
+    s.B.assign(r * r, 0.0);
+    s.t2.assign(r, 0.0);
+    s.t3.assign(r, 0.0);
+    for (int i = 0; i < r; ++i)
+      for (int j = 0; j <= r; ++j) {
+        double m = 0, d = 0;
+        for (size_t q = 0; q < xq.size(); ++q) {
+          m += wq[q] * Vs[q * r + i] * Vt[q * (r + 1) + j];
+          d += wq[q] * Vs[q * r + i] * Gt[q * (r + 1) + j];
+        }
+        if (j == 0) {
+          s.t2[i] = -tau * m;
+          s.t3[i] = -d;
+        } else {
+          s.A[i * r + j - 1] = tau * m;
+          s.B[i * r + j - 1] = d;
+        }
+      }
+    s.G = s.t2;
+    s.Z = s.t3;
+  } else {
+    if (r < 0) throw std::invalid_argument("dG needs r >= 0");
+    const int nt = r + 1;
+    const std::vector<double> pts = radau_right_points(nt);
+    Mat V, G, V0, G0;
+    lagrange_tables(pts, xq, V, G);
+    lagrange_tables(pts, std::vector<double>{0.0}, V0, G0);
+    s.nt = nt;
+    s.A.assign(nt * nt, 0.0);
+    s.B.assign(nt * nt, 0.0);
+    for (int i = 0; i < nt; ++i)
+      for (int j = 0; j < nt; ++j) {
+        double m = 0, d = V0[i] * V0[j];
+        for (size_t q = 0; q < xq.size(); ++q) {
+          m += wq[q] * V[q * nt + i] * V[q * nt + j];
+          d += wq[q] * V[q * nt + i] * G[q * nt + j];
+        }
+        s.A[i * nt + j] = tau * m;
+        s.B[i * nt + j] = d;
+      }
+    s.t2.assign(nt, 0.0);
+    s.t3.assign(V0.begin(), V0.begin() + nt);
+    s.G = s.t3; // DG: returned Gamma = jump, Zeta = 0
+    s.Z = s.t2;
+  }
+  return s;
+}
+
+Mat matmul(int m, int k, int n, const Mat &A, const Mat &B)
+{
+  Mat C(size_t(m) * n, 0.0);
+  for (int i = 0; i < m; ++i)
+    for (int l = 0; l < k; ++l)
+      for (int j = 0; j < n; ++j) C[i * n + j] += A[i * k + l] * B[l * n + j];
+  return C;
+}
+
+Mat inverse(int n, Mat A)
+{
+  Mat I(size_t(n) * n, 0.0);
+  for (int i = 0; i < n; ++i) I[i * n + i] = 1.0;
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::abs(A[r * n + c]) > std::abs(A[piv * n + c])) piv = r;
+    for (int j = 0; j < n; ++j) {
+      std::swap(A[c * n + j], A[piv * n + j]);
+      std::swap(I[c * n + j], I[piv * n + j]);
+    }
+    const double d = A[c * n + c];
+    for (int j = 0; j < n; ++j) {
+      A[c * n + j] /= d;
+      I[c * n + j] /= d;
+    }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = A[r * n + c];
+      for (int j = 0; j < n; ++j) {
+        A[r * n + j] -= f * A[c * n + j];
+        I[r * n + j] -= f * I[c * n + j];
+      }
+    }
+  }
+  return I;
+}
+
+} // namespace
+
+int fe_time_weights(int type, int r, double tau, int nsteps, Mat &Alpha, Mat &Beta, Mat &Gamma,
+                    Mat &Zeta)
+{
+  const Step1 s = single_step(type, r, tau);
+  const int nt = s.nt, nb = nt * nsteps;
+  Alpha.assign(size_t(nb) * nb, 0.0);
+  Beta.assign(size_t(nb) * nb, 0.0);
+  Gamma.assign(nb, 0.0);
+  Zeta.assign(nb, 0.0);
+  for (int it = 0; it < nsteps; ++it) {
+    const int o = it * nt;
+    for (int i = 0; i < nt; ++i)
+      for (int j = 0; j < nt; ++j) {
+        Alpha[(o + i) * nb + o + j] = s.A[i * nt + j];
+        Beta[(o + i) * nb + o + j] = s.B[i * nt + j];
+      }
+    if (it + 1 < nsteps) // last DoF of step `it` feeds step it+1 (fe_time.h:383-391)
+      for (int j = 0; j < nt; ++j) {
+        Alpha[(o + nt + j) * nb + o + nt - 1] = -s.t2[j];
+        Beta[(o + nt + j) * nb + o + nt - 1] = -s.t3[j];
+      }
+  }
+  for (int i = 0; i < nt; ++i) {
+    Gamma[i] = s.G[i];
+    Zeta[i] = s.Z[i];
+  }
+  return nb;
+}
+
+int fe_time_weights_wave(int type, int r, double tau, int nsteps, Mat &AL, Mat &BL, Mat &uK,
+                         Mat &uM, Mat &vM)
+{
+  const Step1 s = single_step(type, r, tau);
+  const int nt = s.nt, nb = nt * nsteps;
+  const Mat &A = s.A, &B = s.B;
+  const std::vector<double> &G = s.G, &Z = s.Z;
+  const Mat BAi = matmul(nt, nt, nt, B, inverse(nt, A));
+  const Mat BAB = matmul(nt, nt, nt, BAi, B);
+  const Mat BAG = matmul(nt, nt, 1, BAi, G);
+  const double all = A[(nt - 1) * nt + nt - 1];
+  const double gxai = G[nt - 1] / all;
+  AL.assign(size_t(nb) * nb, 0.0);
+  BL.assign(size_t(nb) * nb, 0.0);
+  uK.assign(nb, 0.0);
+  uM.assign(nb, 0.0);
+  vM.assign(nb, 0.0);
+  auto al = [&](int i, int j) -> double & { return AL[size_t(i) * nb + j]; };
+  auto bl = [&](int i, int j) -> double & { return BL[size_t(i) * nb + j]; };
+  const double *Blast = &B[(nt - 1) * nt];
+  if (type == 0) {
+    const Mat BAZ = matmul(nt, nt, 1, BAi, Z);
+    std::vector<double> ZmBAG(nt);
+    for (int i = 0; i < nt; ++i) ZmBAG[i] = Z[i] - BAG[i];
+    const double zxai = Z[nt - 1] / all;
+    for (int it = 0; it < nsteps; ++it)
+      for (int jt = 0; jt <= it; ++jt)
+        for (int i = 0; i < nt; ++i) {
+          const int row = i + it * nt;
+          if (it == 0 && jt == 0) {
+            uK[i] = G[i];
+            uM[i] = BAZ[i];
+            vM[i] = ZmBAG[i];
+          } else if (jt == 0) {
+            uM[row] = -zxai * std::pow(gxai, it - 1) * ZmBAG[i];
+            vM[row] = std::pow(gxai, it) * ZmBAG[i];
+          }
+          if (it == jt + 1) {
+            al(row, nt - 1 + jt * nt) = -G[i];
+            bl(row, nt - 1 + jt * nt) = -BAZ[i];
+          }
+          if (it == jt) {
+            for (int j = 0; j < nt; ++j) {
+              al(row, j + it * nt) = A[i * nt + j];
+              bl(row, j + it * nt) = BAB[i * nt + j];
+            }
+          } else {
+            for (int j = 0; j < nt; ++j) {
+              const double zmbab = ZmBAG[i] * Blast[j] / all;
+              double v = -std::pow(gxai, it - jt - 1) * zmbab;
+              if (it > 1 && it - 1 > jt && j == nt - 1)
+                v += std::pow(gxai, it - jt - 2) * zxai * ZmBAG[i];
+              bl(row, j + jt * nt) += v;
+            }
+          }
+        }
+  } else {
+    for (int it = 0; it < nsteps; ++it)
+      for (int i = 0; i < nt; ++i) {
+        if (it == 0) {
+          uM[i] = BAG[i];
+          vM[i] = G[i];
+        }
+        if (it == 1) uM[nt + i] = -G[i] * gxai;
+        if (it + 1 < nsteps)
+          for (int j = 0; j < nt; ++j)
+            bl(j + (it + 1) * nt, i + it * nt) =
+              -G[j] * Blast[i] / all - (i == nt - 1 ? BAG[j] : 0.0);
+        if (it + 2 < nsteps && i == nt - 1)
+          for (int j = 0; j < nt; ++j) bl(j + (it + 2) * nt, i + it * nt) = G[j] * gxai;
+        for (int j = 0; j < nt; ++j) {
+          al(i + it * nt, j + it * nt) = A[i * nt + j];
+          bl(i + it * nt, j + it * nt) = BAB[i * nt + j];
+        }
+      }
+  }
+  return nb;
+}
+
+// --------------------------------------------------------------------------- mesh / coefficient
+
+void mesh_vertices(const int32_t gn[3], const double lo[3], const double up[3], double distort,
+                   uint64_t seed, int32_t z0, int32_t z1, double *out)
+{
+  const double h[3] = {(up[0] - lo[0]) / gn[0], (up[1] - lo[1]) / gn[1], (up[2] - lo[2]) / gn[2]};
+  std::mt19937_64 rng(seed);
+  const int64_t per_plane = int64_t(gn[0] + 1) * (gn[1] + 1);
+  if (distort != 0.0) rng.discard(uint64_t(3) * per_plane * z0);
+  auto u11 = [&]() { return double(rng() >> 11) * (2.0 / 9007199254740992.0) - 1.0; };
+  int64_t o = 0;
+  for (int k = z0; k <= z1; ++k)
+    for (int j = 0; j <= gn[1]; ++j)
+      for (int i = 0; i <= gn[0]; ++i, ++o) {
+        double d[3] = {0, 0, 0};
+        if (distort != 0.0) {
+          d[0] = u11();
+          d[1] = u11();
+          d[2] = u11();
+          const bool interior = i > 0 && i < gn[0] && j > 0 && j < gn[1] && k > 0 && k < gn[2];
+          if (!interior) d[0] = d[1] = d[2] = 0.0;
+        }
+        out[3 * o + 0] = lo[0] + h[0] * i + distort * h[0] * d[0];
+        out[3 * o + 1] = lo[1] + h[1] * j + distort * h[1] * d[1];
+        out[3 * o + 2] = lo[2] + h[2] * k + distort * h[2] * d[2];
+      }
+}
+
+void coefficient_per_cell(const int32_t nc[3], const double *v, double c1, double c2, double c3,
+                          double distort, const int32_t sub[3], const double lo[3],
+                          const double up[3], double *out)
+{
+  std::vector<double> table;
+  double step[3] = {1, 1, 1};
+  if (distort != 0.0) {
+    // boost::random::mt19937(default_seed) + uniform_real_distribution(1-d, 1+d):
+    // one 32-bit draw per value, value = draw / 2^32 * (max-min) + min  (operators.h:905-921)
+    std::mt19937 rng(5489u);
+    table.resize(size_t(sub[0]) * sub[1] * sub[2]);
+    for (double &t : table) {
+      double res;
+      do {
+        res = double(rng()) / 4294967296.0 * (2.0 * distort) + (1.0 - distort);
+      } while (!(res < 1.0 + distort));
+      t = res;
+    }
+    for (int d = 0; d < 3; ++d) step[d] = (up[d] - lo[d]) / sub[d];
+  }
+  const int64_t nvx = nc[0] + 1, nvy = nc[1] + 1;
+  int64_t cell = 0;
+  for (int cz = 0; cz < nc[2]; ++cz)
+    for (int cy = 0; cy < nc[1]; ++cy)
+      for (int cx = 0; cx < nc[0]; ++cx, ++cell) {
+        double c[3] = {0, 0, 0};
+        for (int k = 0; k < 2; ++k)
+          for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) {
+              const int64_t idx = (cx + i) + nvx * ((cy + j) + nvy * int64_t(cz + k));
+              for (int d = 0; d < 3; ++d) c[d] += 0.125 * v[3 * idx + d];
+            }
+        double val = c1;
+        if (c[1] >= 0.2) val = (c[0] < 0.2) ? c2 : c3;
+        if (!table.empty()) {
+          const unsigned ix = unsigned((c[0] - lo[0]) / step[0]);
+          const unsigned iy = unsigned((c[1] - lo[1]) / step[1]);
+          const unsigned iz = unsigned((c[2] - lo[2]) / step[2]);
+          val *= table[(size_t(ix) * sub[1] + iy) * sub[2] + iz]; // Table<3>::fill, last index fastest
+        }
+        out[cell] = val;
+      }
+}
+
+} // namespace stfem

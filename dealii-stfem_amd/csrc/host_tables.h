@@ -1,0 +1,53 @@
+// Host-side numerics of the product library: 1D rules, shape tables in even-odd form,
+// temporal matrices (fe_time.h of the reference), mesh and coefficient helpers.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace stfem {
+
+// ---- 1D rules on [0,1] (deal.II QGauss, QGaussLobatto, QGaussRadau(right)) ----
+void gauss_rule(int n, std::vector<double> &x, std::vector<double> &w);
+std::vector<double> lobatto_points(int n);
+std::vector<double> radau_right_points(int n);
+
+using Mat = std::vector<double>; // row-major
+
+// Lagrange basis on `nodes` evaluated at `x`: V[q*n+a] = l_a(x_q), G[q*n+a] = l_a'(x_q)
+void lagrange_tables(const std::vector<double> &nodes, const std::vector<double> &x, Mat &V, Mat &G);
+
+// Even-odd packing of an n x n matrix X with X[q][a] = sign * X[n-1-q][n-1-a].
+// Layout (h = n/2): ee[q*h+i] | oo[q*h+i] | em[q] | mm[i] | mmm     (last three only for odd n)
+constexpr int eo_size(int n) { return 2 * (n / 2) * (n / 2) + ((n & 1) ? 2 * (n / 2) + 1 : 0); }
+constexpr int EO_MAX = 32; // >= eo_size(7)
+void eo_pack(int n, const Mat &X, double *out);
+
+// Per-degree kernel tables.  Quadrature weights are folded into the tables:
+//   Si  = diag(sqrt w) S            (nodes -> Gauss points, "interpolate")
+//   Dc  = diag(sqrt w) Dcol diag(1/sqrt w)   (collocation derivative at Gauss points)
+// so that M_cell = vol * Si^T Si and K_cell,d = vol/h_d^2 * Si^T Dc^T Dc Si per direction.
+struct ShapeTables {
+  int n; // p+1 == n_q
+  Mat S, D;      // plain S[q][a] = l_a(x_q), D[q][a] = l_a'(x_q)   (nodal -> Gauss)
+  Mat Dcol;      // plain collocation derivative on the Gauss points
+  std::vector<double> xq, wq, nodes;
+  double eo_Si[EO_MAX], eo_SiT[EO_MAX], eo_Dc[EO_MAX], eo_DcT[EO_MAX];
+  double eo_S[EO_MAX], eo_ST[EO_MAX], eo_Dq[EO_MAX], eo_DqT[EO_MAX]; // unweighted S, Dcol
+};
+ShapeTables make_shape_tables(int p);
+
+// ---- temporal matrices ----
+int time_nb(int type, int r, int nsteps);
+int fe_time_weights(int type, int r, double tau, int nsteps, Mat &Alpha, Mat &Beta, Mat &Gamma,
+                    Mat &Zeta);
+int fe_time_weights_wave(int type, int r, double tau, int nsteps, Mat &A_lhs, Mat &B_lhs,
+                         Mat &rhs_uK, Mat &rhs_uM, Mat &rhs_vM);
+
+// ---- mesh / coefficient ----
+void mesh_vertices(const int32_t gn[3], const double lo[3], const double up[3], double distort,
+                   uint64_t seed, int32_t z0, int32_t z1, double *out);
+void coefficient_per_cell(const int32_t nc[3], const double *vertices, double c1, double c2,
+                          double c3, double distort, const int32_t sub[3], const double lo[3],
+                          const double up[3], double *out);
+
+} // namespace stfem

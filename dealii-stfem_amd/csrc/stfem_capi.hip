@@ -1,0 +1,527 @@
+// C-ABI of the MI355X space-time operator apply (see include/stfem.h).
+#include "../../include/stfem.h"
+
+#include "host_tables.h"
+#include "stfem_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace stfem;
+
+namespace {
+
+thread_local std::string g_hip_error;
+
+int hip_fail(hipError_t e, const char *what)
+{
+  g_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+  return STFEM_ERR_HIP;
+}
+#define HIP_TRY(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #call); \
+  } while (0)
+
+} // namespace
+
+struct stfem_ctx {
+  int p = 0, device = 0;
+  int nc[3] = {0, 0, 0}, nd[3] = {0, 0, 0};
+  int64_t ndofs = 0, ncells = 0;
+  int dmask = 0;
+  bool cartesian = false;
+  double lower[3] = {0, 0, 0}, h[3] = {1, 1, 1};
+  ShapeTables tab;
+  std::vector<double> vertices; // host copy (general meshes)
+  double *d_coef[2] = {nullptr, nullptr}; // [0] mass, [1] laplace
+  int coef_layout[2] = {0, 0};
+  double *d_scratch = nullptr; // reductions
+  const char *last_kernel = "";
+};
+
+struct stfem_vec {
+  stfem_ctx *ctx = nullptr;
+  int nb = 0;
+  bool owns = false;
+  std::vector<double *> blk;
+};
+
+extern "C" {
+
+const char *stfem_strerror(int s)
+{
+  switch (s) {
+    case STFEM_OK: return "ok";
+    case STFEM_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case STFEM_ERR_UNSUPPORTED: return "unsupported degree / block count / mesh mode";
+    case STFEM_ERR_HIP: return "HIP runtime error";
+    case STFEM_ERR_NO_DEVICE: return "no HIP device";
+    case STFEM_ERR_SHAPE_MISMATCH: return "block count or size mismatch";
+    case STFEM_ERR_ALIAS: return "dst aliases src";
+    case STFEM_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char *stfem_last_hip_error(void) { return g_hip_error.c_str(); }
+
+int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space, stfem_ctx **out)
+{
+  if (!mesh || !space || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (space->degree < 1 || space->degree > 4) return STFEM_ERR_UNSUPPORTED;
+  if (space->n_q_points_1d != space->degree + 1 || space->n_components != 1)
+    return STFEM_ERR_UNSUPPORTED;
+  for (int d = 0; d < 3; ++d)
+    if (mesh->ncell[d] < 1) return STFEM_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return STFEM_ERR_NO_DEVICE;
+  if (mesh->device < 0 || mesh->device >= ndev) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(mesh->device));
+
+  stfem_ctx *c = new (std::nothrow) stfem_ctx;
+  if (!c) return STFEM_ERR_OUT_OF_MEMORY;
+  c->p = space->degree;
+  c->device = mesh->device;
+  c->ndofs = c->ncells = 1;
+  for (int d = 0; d < 3; ++d) {
+    c->nc[d] = mesh->ncell[d];
+    c->nd[d] = c->p * c->nc[d] + 1;
+    c->ndofs *= c->nd[d];
+    c->ncells *= c->nc[d];
+  }
+  c->dmask = mesh->dirichlet_mask & 63;
+  try {
+    c->tab = make_shape_tables(c->p);
+  } catch (...) {
+    delete c;
+    return STFEM_ERR_INVALID_ARGUMENT;
+  }
+  if (!mesh->vertices) {
+    c->cartesian = true;
+    for (int d = 0; d < 3; ++d) {
+      c->lower[d] = mesh->lower[d];
+      c->h[d] = (mesh->upper[d] - mesh->lower[d]) / c->nc[d];
+      if (!(c->h[d] > 0)) {
+        delete c;
+        return STFEM_ERR_INVALID_ARGUMENT;
+      }
+    }
+  } else {
+    // recognise an axis-aligned uniform box (deal.II compresses such cells as "Cartesian")
+    const int64_t nvx = c->nc[0] + 1, nvy = c->nc[1] + 1, nvz = c->nc[2] + 1;
+    const int64_t nv = nvx * nvy * nvz;
+    const double *v = mesh->vertices;
+    double lo[3], up[3];
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = v[d];
+      up[d] = v[3 * (nv - 1) + d];
+      c->lower[d] = lo[d];
+      c->h[d] = (up[d] - lo[d]) / c->nc[d];
+    }
+    bool cart = c->h[0] > 0 && c->h[1] > 0 && c->h[2] > 0;
+    const double tol = 1e-13 * std::max({std::abs(up[0] - lo[0]), std::abs(up[1] - lo[1]),
+                                         std::abs(up[2] - lo[2]), 1e-300});
+    for (int64_t k = 0, o = 0; k < nvz && cart; ++k)
+      for (int64_t j = 0; j < nvy && cart; ++j)
+        for (int64_t i = 0; i < nvx; ++i, ++o) {
+          if (std::abs(v[3 * o] - (lo[0] + c->h[0] * i)) > tol ||
+              std::abs(v[3 * o + 1] - (lo[1] + c->h[1] * j)) > tol ||
+              std::abs(v[3 * o + 2] - (lo[2] + c->h[2] * k)) > tol) {
+            cart = false;
+            break;
+          }
+        }
+    c->cartesian = cart;
+    c->vertices.assign(v, v + 3 * nv);
+  }
+  if (hipMalloc(&c->d_scratch, 4096) != hipSuccess) {
+    delete c;
+    return STFEM_ERR_OUT_OF_MEMORY;
+  }
+  *out = c;
+  return STFEM_OK;
+}
+
+void stfem_ctx_destroy(stfem_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (double *&p : c->d_coef)
+    if (p) (void)hipFree(p);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  delete c;
+}
+
+int64_t stfem_n_dofs(const stfem_ctx *c) { return c ? c->ndofs : 0; }
+int64_t stfem_n_cells(const stfem_ctx *c) { return c ? c->ncells : 0; }
+int stfem_is_cartesian(const stfem_ctx *c) { return c && c->cartesian ? 1 : 0; }
+const char *stfem_last_kernel_name(const stfem_ctx *c) { return c ? c->last_kernel : ""; }
+
+int stfem_set_coefficient(stfem_ctx *c, int which, int layout, const double *host)
+{
+  if (!c || which < 0 || which > 1 || layout < 0 || layout > 2) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->d_coef[which]) {
+    HIP_TRY(hipFree(c->d_coef[which]));
+    c->d_coef[which] = nullptr;
+  }
+  c->coef_layout[which] = 0;
+  if (layout == 0) return STFEM_OK;
+  if (!host) return STFEM_ERR_INVALID_ARGUMENT;
+  const int nq = c->p + 1;
+  const size_t n = size_t(c->ncells) * (layout == 2 ? size_t(nq) * nq * nq : 1);
+  if (hipMalloc(&c->d_coef[which], n * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+  HIP_TRY(hipMemcpy(c->d_coef[which], host, n * sizeof(double), hipMemcpyHostToDevice));
+  c->coef_layout[which] = layout;
+  return STFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------ vectors
+
+int stfem_vector_create(stfem_ctx *c, int nb, stfem_vec **out)
+{
+  if (!c || !out || nb < 1) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  stfem_vec *v = new (std::nothrow) stfem_vec;
+  if (!v) return STFEM_ERR_OUT_OF_MEMORY;
+  v->ctx = c;
+  v->nb = nb;
+  v->owns = true;
+  v->blk.assign(nb, nullptr);
+  for (int b = 0; b < nb; ++b) {
+    if (hipMalloc(&v->blk[b], size_t(c->ndofs) * sizeof(double)) != hipSuccess) {
+      stfem_vector_destroy(v);
+      return STFEM_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemset(v->blk[b], 0, size_t(c->ndofs) * sizeof(double)) != hipSuccess) {
+      stfem_vector_destroy(v);
+      return STFEM_ERR_HIP;
+    }
+  }
+  *out = v;
+  return STFEM_OK;
+}
+
+int stfem_vector_wrap(stfem_ctx *c, int nb, void *const *blocks, stfem_vec **out)
+{
+  if (!c || !out || nb < 1 || !blocks) return STFEM_ERR_INVALID_ARGUMENT;
+  stfem_vec *v = new (std::nothrow) stfem_vec;
+  if (!v) return STFEM_ERR_OUT_OF_MEMORY;
+  v->ctx = c;
+  v->nb = nb;
+  v->owns = false;
+  for (int b = 0; b < nb; ++b) {
+    if (!blocks[b]) {
+      delete v;
+      return STFEM_ERR_INVALID_ARGUMENT;
+    }
+    v->blk.push_back(static_cast<double *>(blocks[b]));
+  }
+  *out = v;
+  return STFEM_OK;
+}
+
+void stfem_vector_destroy(stfem_vec *v)
+{
+  if (!v) return;
+  if (v->owns) {
+    (void)hipSetDevice(v->ctx->device);
+    for (double *p : v->blk)
+      if (p) (void)hipFree(p);
+  }
+  delete v;
+}
+
+int stfem_vector_n_blocks(const stfem_vec *v) { return v ? v->nb : 0; }
+void *stfem_vector_block(const stfem_vec *v, int b)
+{
+  return (v && b >= 0 && b < v->nb) ? v->blk[b] : nullptr;
+}
+
+int stfem_vector_upload(stfem_vec *v, const double *const *host)
+{
+  if (!v || !host) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  for (int b = 0; b < v->nb; ++b)
+    HIP_TRY(hipMemcpy(v->blk[b], host[b], size_t(v->ctx->ndofs) * sizeof(double), hipMemcpyHostToDevice));
+  return STFEM_OK;
+}
+
+int stfem_vector_download(const stfem_vec *v, double *const *host)
+{
+  if (!v || !host) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (int b = 0; b < v->nb; ++b)
+    HIP_TRY(hipMemcpy(host[b], v->blk[b], size_t(v->ctx->ndofs) * sizeof(double), hipMemcpyDeviceToHost));
+  return STFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------ operator
+
+static void fill_common(const stfem_ctx *c, SweepParams &prm)
+{
+  std::memset(&prm, 0, sizeof(prm));
+  prm.ncx = c->nc[0]; prm.ncy = c->nc[1]; prm.ncz = c->nc[2];
+  prm.nx = c->nd[0]; prm.ny = c->nd[1]; prm.nz = c->nd[2];
+  prm.ncells = c->ncells;
+  prm.dmask = c->dmask;
+  prm.vol = c->h[0] * c->h[1] * c->h[2];
+  prm.ihx2 = 1.0 / (c->h[0] * c->h[0]);
+  prm.ihy2 = 1.0 / (c->h[1] * c->h[1]);
+  prm.ihz2 = 1.0 / (c->h[2] * c->h[2]);
+  const int ne = eo_size(c->p + 1);
+  std::memcpy(prm.eo_Si, c->tab.eo_Si, ne * sizeof(double));
+  std::memcpy(prm.eo_SiT, c->tab.eo_SiT, ne * sizeof(double));
+  std::memcpy(prm.eo_Dc, c->tab.eo_Dc, ne * sizeof(double));
+  std::memcpy(prm.eo_DcT, c->tab.eo_DcT, ne * sizeof(double));
+}
+
+// a(j,i), b(j,i): effective nbo x nbi matrices (row-major)
+static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,
+                       const std::vector<double> &b, stfem_vec *dst, const stfem_vec *src, int add,
+                       bool use_lap_coef, bool use_mass_coef, void *stream)
+{
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int j = 0; j < nbo; ++j)
+    for (int i = 0; i < nbi; ++i)
+      if (dst->blk[j] == src->blk[i]) return STFEM_ERR_ALIAS;
+  if (!c->cartesian) return STFEM_ERR_UNSUPPORTED;
+  for (int w = 0; w < 2; ++w)
+    if (c->coef_layout[w] == 2) return STFEM_ERR_UNSUPPORTED;
+  if (!add)
+    for (int j = 0; j < nbo; ++j)
+      HIP_TRY(hipMemsetAsync(dst->blk[j], 0, size_t(c->ndofs) * sizeof(double), st));
+  SweepParams prm;
+  fill_common(c, prm);
+  prm.coef_lap = use_lap_coef ? c->d_coef[1] : nullptr;
+  prm.coef_mass = use_mass_coef ? c->d_coef[0] : nullptr;
+  for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS)
+    for (int i0 = 0; i0 < nbi; i0 += MAX_BLOCKS) {
+      const int tj = std::min(MAX_BLOCKS, nbo - j0), ti = std::min(MAX_BLOCKS, nbi - i0);
+      bool nonzero = false;
+      for (int j = 0; j < tj; ++j)
+        for (int i = 0; i < ti; ++i) {
+          prm.alpha[j * ti + i] = a[size_t(j0 + j) * nbi + i0 + i];
+          prm.beta[j * ti + i] = b[size_t(j0 + j) * nbi + i0 + i];
+          nonzero = nonzero || prm.alpha[j * ti + i] != 0.0 || prm.beta[j * ti + i] != 0.0;
+        }
+      if (!nonzero) continue; // the reference skips exact zeros too (operators.h:551,556)
+      prm.nbo = tj;
+      prm.nbi = ti;
+      for (int j = 0; j < tj; ++j) prm.dst[j] = dst->blk[j0 + j];
+      for (int i = 0; i < ti; ++i) prm.src[i] = src->blk[i0 + i];
+      const int rc = launch_cart_atomic(c->p, prm, st);
+      if (rc == -3) return hip_fail(hipGetLastError(), "kernel launch");
+      if (rc != 0) return STFEM_ERR_UNSUPPORTED;
+      c->last_kernel = cart_atomic_name(c->p, std::max(tj, ti));
+    }
+  return STFEM_OK;
+}
+
+int stfem_st_vmult(stfem_ctx *c, int nrows, int ncols, const double *alpha, const double *beta,
+                   int transpose, int add, stfem_vec *dst, const stfem_vec *src, void *stream)
+{
+  if (!c || !alpha || !beta || !dst || !src || nrows < 1 || ncols < 1)
+    return STFEM_ERR_INVALID_ARGUMENT;
+  if (dst->ctx != c || src->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  const int nbi = transpose ? nrows : ncols, nbo = transpose ? ncols : nrows;
+  if (src->nb != nbi || dst->nb != nbo) return STFEM_ERR_SHAPE_MISMATCH;
+  std::vector<double> a(size_t(nbo) * nbi), b(size_t(nbo) * nbi);
+  for (int j = 0; j < nbo; ++j)
+    for (int i = 0; i < nbi; ++i) {
+      const size_t s = transpose ? size_t(i) * ncols + j : size_t(j) * ncols + i;
+      a[size_t(j) * nbi + i] = alpha[s];
+      b[size_t(j) * nbi + i] = beta[s];
+    }
+  // K = MatrixFreeOperator(0,1), M = MatrixFreeOperator(1,0); a coefficient replaces the 1
+  return apply_tiled(c, nbo, nbi, a, b, dst, src, add, c->coef_layout[1] != 0,
+                     c->coef_layout[0] != 0, stream);
+}
+
+int stfem_space_vmult(stfem_ctx *c, double ms, double ls, stfem_vec *dst, const stfem_vec *src,
+                      void *stream)
+{
+  if (!c || !dst || !src) return STFEM_ERR_INVALID_ARGUMENT;
+  if (dst->ctx != c || src->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (dst->nb != 1 || src->nb != 1) return STFEM_ERR_SHAPE_MISMATCH;
+  // operators.h:1152-1162: term present iff scaling != 0; coefficient (if any) replaces it
+  const bool lc = ls != 0.0 && c->coef_layout[1] != 0, mc = ms != 0.0 && c->coef_layout[0] != 0;
+  std::vector<double> a{ls != 0.0 ? (lc ? 1.0 : ls) : 0.0}, b{ms != 0.0 ? (mc ? 1.0 : ms) : 0.0};
+  return apply_tiled(c, 1, 1, a, b, dst, src, 0, lc, mc, stream);
+}
+
+int stfem_diagonal(stfem_ctx *, double, double, stfem_vec *, void *) { return STFEM_ERR_UNSUPPORTED; }
+
+// ------------------------------------------------------------------------------------ BLAS-1 / halo
+
+__global__ void axpy_blocks_kernel(int64_t n, int nterms, const double *const *xs, const double *coef, double *y)
+{
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    double acc = y[i];
+    for (int t = 0; t < nterms; ++t) acc = fma(coef[t], xs[t][i], acc);
+    y[i] = acc;
+  }
+}
+
+struct AxpyArgs {
+  const double *x[MAX_BLOCKS];
+  double coef[MAX_BLOCKS];
+  int n;
+};
+__global__ __launch_bounds__(256) void axpy_kernel(int64_t n, AxpyArgs a, double *y)
+{
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    double acc = y[i];
+    for (int t = 0; t < a.n; ++t) acc = fma(a.coef[t], a.x[t][i], acc);
+    y[i] = acc;
+  }
+}
+
+int stfem_tensorproduct_add(stfem_ctx *c, int nrows, int ncols, const double *A, stfem_vec *cv,
+                            const stfem_vec *b, void *stream)
+{
+  if (!c || !A || !cv || !b) return STFEM_ERR_INVALID_ARGUMENT;
+  if (cv->nb != nrows || b->nb != ncols) return STFEM_ERR_SHAPE_MISMATCH;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int i = 0; i < nrows; ++i)
+    for (int j0 = 0; j0 < ncols; j0 += MAX_BLOCKS) {
+      AxpyArgs a;
+      a.n = 0;
+      for (int j = j0; j < std::min(ncols, j0 + MAX_BLOCKS); ++j)
+        if (A[size_t(i) * ncols + j] != 0.0) { // operators.h:246
+          if (cv->blk[i] == b->blk[j]) return STFEM_ERR_ALIAS;
+          a.x[a.n] = b->blk[j];
+          a.coef[a.n++] = A[size_t(i) * ncols + j];
+        }
+      if (a.n == 0) continue;
+      const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 256 * 16);
+      hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, st, c->ndofs, a, cv->blk[i]);
+    }
+  return STFEM_OK;
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const double *a, const double *b, double *out)
+{
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    s = fma(a[i], b[i], s);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+int stfem_dot(stfem_ctx *c, const stfem_vec *a, const stfem_vec *b, int64_t n_own, double *out, void *stream)
+{
+  if (!c || !a || !b || !out || a->nb != b->nb) return STFEM_ERR_INVALID_ARGUMENT;
+  if (n_own <= 0 || n_own > c->ndofs) n_own = c->ndofs;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(double), st));
+  const unsigned grid = (unsigned)std::min<int64_t>((n_own + 255) / 256, 1024);
+  for (int blk = 0; blk < a->nb; ++blk)
+    hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(256), 0, st, n_own, a->blk[blk], b->blk[blk], c->d_scratch);
+  HIP_TRY(hipMemcpyAsync(out, c->d_scratch, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return STFEM_OK;
+}
+
+__global__ __launch_bounds__(256) void plane_copy_kernel(int64_t n, const double *src, double *dst, int add)
+{
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    dst[i] = add ? dst[i] + src[i] : src[i];
+}
+
+int stfem_plane_pack(stfem_ctx *c, const stfem_vec *v, int iz, void *buf, void *stream)
+{
+  if (!c || !v || !buf || iz < 0 || iz >= c->nd[2]) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t plane = int64_t(c->nd[0]) * c->nd[1];
+  for (int b = 0; b < v->nb; ++b)
+    HIP_TRY(hipMemcpyAsync(static_cast<double *>(buf) + b * plane, v->blk[b] + plane * iz,
+                           plane * sizeof(double), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return STFEM_OK;
+}
+
+int stfem_plane_unpack(stfem_ctx *c, stfem_vec *v, int iz, const void *buf, int add, void *stream)
+{
+  if (!c || !v || !buf || iz < 0 || iz >= c->nd[2]) return STFEM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t plane = int64_t(c->nd[0]) * c->nd[1];
+  const unsigned grid = (unsigned)std::min<int64_t>((plane + 255) / 256, 4096);
+  for (int b = 0; b < v->nb; ++b)
+    hipLaunchKernelGGL(plane_copy_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), plane,
+                       static_cast<const double *>(buf) + b * plane, v->blk[b] + plane * iz, add);
+  return STFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------ host helpers
+
+int stfem_fe_time_weights(int type, int r, double tau, int ns, double *Alpha, double *Beta,
+                          double *Gamma, double *Zeta)
+{
+  if ((type != 0 && type != 1) || ns < 1 || !Alpha || !Beta || !Gamma || !Zeta || r > 8)
+    return STFEM_ERR_INVALID_ARGUMENT;
+  try {
+    Mat A, B, G, Z;
+    const int nb = fe_time_weights(type, r, tau, ns, A, B, G, Z);
+    std::copy(A.begin(), A.end(), Alpha);
+    std::copy(B.begin(), B.end(), Beta);
+    std::copy(G.begin(), G.end(), Gamma);
+    std::copy(Z.begin(), Z.end(), Zeta);
+    return nb;
+  } catch (...) {
+    return STFEM_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int stfem_fe_time_weights_wave(int type, int r, double tau, int ns, double *AL, double *BL,
+                               double *uK, double *uM, double *vM)
+{
+  if ((type != 0 && type != 1) || ns < 1 || !AL || !BL || !uK || !uM || !vM || r > 8)
+    return STFEM_ERR_INVALID_ARGUMENT;
+  try {
+    Mat a, b, k, m, v;
+    const int nb = fe_time_weights_wave(type, r, tau, ns, a, b, k, m, v);
+    std::copy(a.begin(), a.end(), AL);
+    std::copy(b.begin(), b.end(), BL);
+    std::copy(k.begin(), k.end(), uK);
+    std::copy(m.begin(), m.end(), uM);
+    std::copy(v.begin(), v.end(), vM);
+    return nb;
+  } catch (...) {
+    return STFEM_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int stfem_mesh_vertices(const int32_t gn[3], const double lo[3], const double up[3], double distort,
+                        uint64_t seed, int32_t z0, int32_t z1, double *out)
+{
+  if (!gn || !lo || !up || !out || z0 < 0 || z1 > gn[2] || z0 >= z1) return STFEM_ERR_INVALID_ARGUMENT;
+  mesh_vertices(gn, lo, up, distort, seed, z0, z1, out);
+  return STFEM_OK;
+}
+
+int stfem_coefficient_per_cell(const int32_t nc[3], const double *vertices, double c1, double c2,
+                               double c3, double distort, const int32_t sub[3], const double lo[3],
+                               const double up[3], double *out)
+{
+  if (!nc || !vertices || !sub || !lo || !up || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  coefficient_per_cell(nc, vertices, c1, c2, c3, distort, sub, lo, up, out);
+  return STFEM_OK;
+}
+
+} // extern "C"

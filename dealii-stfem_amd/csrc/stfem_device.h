@@ -1,0 +1,134 @@
+// Device-side building blocks of the fused space-time cell sweep (gfx950, wave64).
+//
+// Thread layout ("plane per thread"): a cell's (p+1)^3 tensor of one temporal block is held by
+// N = p+1 lanes of ONE wave, each owning one N x N plane in registers.  Two of the three 1D
+// contractions of every sum-factorisation stage run entirely in registers; the third direction
+// is reached by a transpose through a wave-private LDS slab (no workgroup barrier: LDS
+// operations of one wave execute in order).
+//
+//   layout A: lane index = z-plane,  registers [y][x]
+//   layout B: lane index = x-plane,  registers [y][z]
+//
+// 1D matrices are applied in even-odd form (Kopriva / Kronbichler-Kormann): 21 instead of 25
+// multiply-adds for N = 5, and only eo_size(N) distinct constants, which live in SGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace stfem {
+
+#define STFEM_UNROLL _Pragma("unroll")
+
+__host__ __device__ constexpr int eo_size_c(int n)
+{
+  return 2 * (n / 2) * (n / 2) + ((n & 1) ? 2 * (n / 2) + 1 : 0);
+}
+
+// y = X x for an N x N matrix with X[q][a] = SIGN * X[N-1-q][N-1-a], constants packed by
+// host_tables.cpp::eo_pack.  `c` must be wave-uniform (kernel argument -> SGPRs).
+template <int N, int SIGN>
+__device__ __forceinline__ void eo_apply(const double *__restrict__ c, const double (&x)[N],
+                                         double (&y)[N])
+{
+  constexpr int H = N / 2;
+  constexpr bool ODD = (N & 1) != 0;
+  double xe[H > 0 ? H : 1], xo[H > 0 ? H : 1];
+  STFEM_UNROLL
+  for (int i = 0; i < H; ++i) {
+    xe[i] = x[i] + x[N - 1 - i];
+    xo[i] = x[i] - x[N - 1 - i];
+  }
+  STFEM_UNROLL
+  for (int q = 0; q < H; ++q) {
+    double a = c[q * H] * xe[0];
+    double b = c[H * H + q * H] * xo[0];
+    STFEM_UNROLL
+    for (int i = 1; i < H; ++i) {
+      a = fma(c[q * H + i], xe[i], a);
+      b = fma(c[H * H + q * H + i], xo[i], b);
+    }
+    if (ODD) a = fma(c[2 * H * H + q], x[H], a);
+    y[q] = a + b;
+    y[N - 1 - q] = SIGN > 0 ? a - b : b - a;
+  }
+  if (ODD) {
+    double m;
+    if (SIGN > 0) {
+      m = c[2 * H * H + 2 * H] * x[H];
+      STFEM_UNROLL
+      for (int i = 0; i < H; ++i) m = fma(c[2 * H * H + H + i], xe[i], m);
+    } else {
+      m = c[2 * H * H + H] * xo[0];
+      STFEM_UNROLL
+      for (int i = 1; i < H; ++i) m = fma(c[2 * H * H + H + i], xo[i], m);
+    }
+    y[H] = m;
+  }
+}
+
+// In-place sweep over an N x N register plane P[s*N + f] (s slow, f fast index).
+// ALONG_FAST: contract the fast index for every slow index; else contract the slow index.
+template <int N, int SIGN, bool ALONG_FAST>
+__device__ __forceinline__ void plane_sweep(const double *__restrict__ c, double (&P)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    double x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
+    eo_apply<N, SIGN>(c, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) (ALONG_FAST ? P[o * N + i] : P[i * N + o]) = y[i];
+  }
+}
+
+// R += s * D^T ( D U ) along one in-register direction (collocation Laplacian of that
+// direction with the quadrature weights folded into D).  D antisymmetric-type, as is D^T.
+template <int N, bool ALONG_FAST>
+__device__ __forceinline__ void plane_laplace_acc(const double *__restrict__ cD,
+                                                  const double *__restrict__ cDT, double s,
+                                                  const double (&U)[N * N], double (&R)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    double x[N], t[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? U[o * N + i] : U[i * N + o];
+    eo_apply<N, -1>(cD, x, t);
+    eo_apply<N, -1>(cDT, t, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double &r = ALONG_FAST ? R[o * N + i] : R[i * N + o];
+      r = fma(s, y[i], r);
+    }
+  }
+}
+
+// Same, overwriting U in place with s * D^T D U (used for the direction that needs its own
+// layout, whose result is then transposed and added).
+template <int N, bool ALONG_FAST>
+__device__ __forceinline__ void plane_laplace_inplace(const double *__restrict__ cD,
+                                                      const double *__restrict__ cDT, double s,
+                                                      double (&U)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    double x[N], t[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? U[o * N + i] : U[i * N + o];
+    eo_apply<N, -1>(cD, x, t);
+    eo_apply<N, -1>(cDT, t, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) (ALONG_FAST ? U[o * N + i] : U[i * N + o]) = s * y[i];
+  }
+}
+
+// Orders the LDS traffic of ONE wave: everything this wave wrote before is visible to its
+// later reads.  No instruction is emitted beyond what the compiler needs for its own ordering.
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+} // namespace stfem

@@ -1,0 +1,33 @@
+// Kernel parameter block and launch entry points shared by stfem_kernels.hip and stfem_capi.hip.
+#pragma once
+#include <cstdint>
+
+namespace stfem {
+
+constexpr int MAX_BLOCKS = 8; // temporal blocks handled by one launch (larger systems are tiled)
+constexpr int EO_N = 16;      // >= eo_size(5)
+
+struct SweepParams {
+  const double *src[MAX_BLOCKS];
+  double *dst[MAX_BLOCKS];
+  double alpha[MAX_BLOCKS * MAX_BLOCKS]; // [j*nbi + i], already transposed for Tvmult
+  double beta[MAX_BLOCKS * MAX_BLOCKS];
+  int nbi, nbo;         // input (source) and output (destination) temporal blocks
+  int ncx, ncy, ncz;    // cells per direction
+  int nx, ny, nz;       // DoFs per direction
+  int64_t ncells;
+  int dmask;            // Dirichlet faces
+  double vol;           // hx*hy*hz
+  double ihx2, ihy2, ihz2;
+  const double *coef_lap;  // per cell or nullptr
+  const double *coef_mass; // per cell or nullptr
+  double eo_Si[EO_N], eo_SiT[EO_N], eo_Dc[EO_N], eo_DcT[EO_N];
+};
+
+// Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.
+// Variant "atomic": result scattered with global fp64 atomics into a pre-zeroed dst.
+// Returns 0, or -2 if (p, nbm) has no instantiation.
+int launch_cart_atomic(int p, const SweepParams &prm, void *stream);
+const char *cart_atomic_name(int p, int nbm);
+
+} // namespace stfem

@@ -1,0 +1,104 @@
+"""z-slab sharding of the structured mesh over ranks + interface-plane exchange.
+
+The reference shards the spatial mesh over MPI ranks (parallel::distributed::Triangulation,
+tests/tp_01.cc:80); every spatial cell loop is bracketed by a ghost update of src and a
+compress(add) of dst inside MatrixFree::cell_loop (include/operators.h:1016-1017).  Here:
+
+  * rank g owns cell layers [z0, z1) of the global mesh; its local DoF box has
+    nz_local = p*(z1-z0)+1 planes; its TOP plane is the ghost copy of the upper
+    neighbour's BOTTOM plane (owner = upper rank), exactly one shared plane per interface.
+  * the fused kernel needs ONE exchange per space-time vmult (all temporal blocks packed
+    together) instead of the reference's 2*n_blocks: after the local cell sweep both copies of
+    an interface plane hold partial sums; `exchange_add` sends each partial to the other side
+    and adds, which leaves owner and ghost consistent (compress(add) + update_ghost_values in
+    one step).  Ring neighbours only -> each message rides one xGMI link.
+
+Only torch.distributed point-to-point is used (backend "nccl" = RCCL on the GPUs, "gloo" in
+the CPU tests).  The plane buffers are torch tensors; packing/unpacking on the GPU goes through
+the C-ABI (stfem_plane_pack / stfem_plane_unpack) via the callables handed in.
+"""
+from dataclasses import dataclass
+
+
+@dataclass
+class Slab:
+    rank: int
+    world: int
+    z0: int  # first owned cell layer
+    z1: int  # one past the last
+    global_ncell: tuple
+
+    @property
+    def ncell(self):
+        return (self.global_ncell[0], self.global_ncell[1], self.z1 - self.z0)
+
+    @property
+    def has_lower(self):
+        return self.rank > 0
+
+    @property
+    def has_upper(self):
+        return self.rank < self.world - 1
+
+    def dirichlet_mask(self, global_mask=63):
+        """Partition interfaces carry no constraints (include/stfem.h: stfem_mesh_desc)."""
+        m = global_mask
+        if self.has_lower:
+            m &= ~16
+        if self.has_upper:
+            m &= ~32
+        return m
+
+    def n_owned_planes(self, degree):
+        """Planes this rank owns: all but the top ghost plane (the last rank owns its top)."""
+        nz = degree * (self.z1 - self.z0) + 1
+        return nz - 1 if self.has_upper else nz
+
+
+def make_slab(global_ncell, rank, world):
+    nzc = global_ncell[2]
+    if world > nzc:
+        raise ValueError("more ranks than cell layers")
+    base, extra = divmod(nzc, world)
+    z0 = rank * base + min(rank, extra)
+    z1 = z0 + base + (1 if rank < extra else 0)
+    return Slab(rank, world, z0, z1, tuple(global_ncell))
+
+
+def exchange_add(slab, top_send, bottom_send, top_recv, bottom_recv, dist):
+    """Ring neighbour exchange of the packed interface planes (all temporal blocks in one message).
+
+    top_send/bottom_send: this rank's partial sums of its top / bottom plane (torch tensors);
+    top_recv/bottom_recv: receive buffers for the neighbour's partials of the same planes.
+    Returns the list of work handles; caller waits, then adds top_recv into its top plane and
+    bottom_recv into its bottom plane."""
+    ops = []
+    if slab.has_upper:
+        ops.append(dist.P2POp(dist.isend, top_send, slab.rank + 1))
+        ops.append(dist.P2POp(dist.irecv, top_recv, slab.rank + 1))
+    if slab.has_lower:
+        ops.append(dist.P2POp(dist.isend, bottom_send, slab.rank - 1))
+        ops.append(dist.P2POp(dist.irecv, bottom_recv, slab.rank - 1))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def sharded_vmult(slab, local_vmult, pack_plane, unpack_add_plane, bufs, dist):
+    """One space-time vmult on a z-slab decomposition.
+
+    local_vmult():            runs the cell sweep on this rank's slab (dst overwritten)
+    pack_plane(iz, buf):      buf <- dst planes iz of all blocks
+    unpack_add_plane(iz, buf): dst planes iz of all blocks += buf
+    bufs: dict with tensors 'ts','bs','tr','br' (top/bottom send/recv), each n_blocks*nx*ny."""
+    local_vmult()
+    if slab.world == 1:
+        return
+    if slab.has_upper:
+        pack_plane(-1, bufs["ts"])
+    if slab.has_lower:
+        pack_plane(0, bufs["bs"])
+    for w in exchange_add(slab, bufs["ts"], bufs["bs"], bufs["tr"], bufs["br"], dist):
+        w.wait()
+    if slab.has_upper:
+        unpack_add_plane(-1, bufs["tr"])
+    if slab.has_lower:
+        unpack_add_plane(0, bufs["br"])

@@ -1,0 +1,169 @@
+/*
+ * stfem.h -- C-ABI of the MI355X-native matrix-free space-time operator apply.
+ *
+ * This is the drop-in boundary for ONE hot path of immaaane/dealii-stfem: the
+ * space-time operator application  dst = (Alpha (x) K + Beta (x) M) src.
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference repository).  The reference has no FFI: its boundary is the
+ * duck-typed C++ operator concept (vmult/Tvmult/...) consumed by deal.II
+ * solvers.  dealii-stfem_amd/host/stfem/operators.h holds header-only C++
+ * classes with the reference's class and method names on top of this ABI;
+ * INTEGRATION.md shows the deal.II-side glue.
+ *
+ * Conventions: plain pointers and sizes only; all functions return 0 on
+ * success or a negative stfem_status; nothing throws across the boundary.
+ * "device pointer" = HIP device memory of the context's device.  `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream).  Calls are
+ * asynchronous on `stream` unless noted.  One host thread per context.
+ *
+ * DoF numbering: lexicographic over the structured mesh,
+ * index = ix + nx*(iy + ny*iz), nx = p*ncell[0]+1, x fastest.
+ */
+#ifndef STFEM_H
+#define STFEM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  STFEM_OK = 0,
+  STFEM_ERR_INVALID_ARGUMENT = -1,
+  STFEM_ERR_UNSUPPORTED = -2, /* degree / block count / mode not built */
+  STFEM_ERR_HIP = -3,         /* a HIP runtime call failed: see stfem_last_hip_error */
+  STFEM_ERR_NO_DEVICE = -4,
+  STFEM_ERR_SHAPE_MISMATCH = -5,
+  STFEM_ERR_ALIAS = -6, /* vmult(dst, src) with dst == src (reference forbids it too) */
+  STFEM_ERR_OUT_OF_MEMORY = -7
+} stfem_status;
+
+typedef struct stfem_ctx stfem_ctx; /* replaces MatrixFree + MatrixFreeOperator state */
+typedef struct stfem_vec stfem_vec; /* replaces LinearAlgebra::distributed::BlockVector */
+
+/* Mesh of one rank: a structured block of hexahedra (MappingQ1 geometry).
+ * Replaces GridGenerator::subdivided_hyper_rectangle + refine_global +
+ * GridTools::distort_random as used by tests/tp_01.cc:82-90. */
+typedef struct {
+  int32_t ncell[3];       /* cells per direction on this rank */
+  const double *vertices; /* host, (ncell+1)^3 * 3, x fastest, xyz interleaved; NULL = Cartesian box */
+  double lower[3];        /* used when vertices == NULL */
+  double upper[3];
+  int32_t dirichlet_mask; /* bit0 -x, bit1 +x, bit2 -y, bit3 +y, bit4 -z, bit5 +z: faces carrying
+                             homogeneous Dirichlet constraints (make_zero_boundary_constraints,
+                             tests/tp_01.cc:98).  Partition interfaces are NOT set. */
+  int32_t device;         /* HIP device ordinal */
+} stfem_mesh_desc;
+
+/* Replaces FE_Q<dim>(p) + QGauss<dim>(p+1) of tests/tp_01.cc:76-77. */
+typedef struct {
+  int32_t degree;       /* p, 1..4 */
+  int32_t n_q_points_1d; /* must be degree+1 */
+  int32_t n_components; /* must be 1 (scalar path) */
+} stfem_space_desc;
+
+/* MatrixFreeOperator ctor (include/operators.h:973-1004): builds device tables. Synchronous. */
+int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space, stfem_ctx **out);
+void stfem_ctx_destroy(stfem_ctx *ctx);
+/* MatrixFreeOperator::m() (operators.h:1047-1051): spatial DoFs on this rank */
+int64_t stfem_n_dofs(const stfem_ctx *ctx);
+int64_t stfem_n_cells(const stfem_ctx *ctx);
+/* 1 if the mesh was recognised as an axis-aligned uniform box (Cartesian fast path) */
+int stfem_is_cartesian(const stfem_ctx *ctx);
+
+/* MatrixFreeOperator::evaluate_coefficient (operators.h:1060-1087).
+ * which: 0 = mass coefficient (the M operator), 1 = laplace coefficient (the K operator).
+ * layout: 0 = clear (scalings 1 are used), 1 = one value per cell, 2 = one value per
+ * (cell, quadrature point), host array [cell*nq^3 + q], q = qx + nq*(qy + nq*qz).
+ * As in the reference the coefficient REPLACES the scaling.  Synchronous. */
+int stfem_set_coefficient(stfem_ctx *ctx, int which, int layout, const double *host_values);
+
+/* initialize_dof_vector (operators.h:1006-1011, 648-662): n_blocks spatial vectors of
+ * stfem_n_dofs doubles each, zero-initialised. */
+int stfem_vector_create(stfem_ctx *ctx, int n_blocks, stfem_vec **out);
+/* View caller-owned device memory (e.g. the arrays behind a deal.II
+ * LinearAlgebra::distributed::BlockVector<double, MemorySpace::Default>): one device pointer
+ * per block, each stfem_n_dofs doubles.  Not freed by stfem_vector_destroy. */
+int stfem_vector_wrap(stfem_ctx *ctx, int n_blocks, void *const *device_blocks, stfem_vec **out);
+void stfem_vector_destroy(stfem_vec *v);
+int stfem_vector_n_blocks(const stfem_vec *v);
+void *stfem_vector_block(const stfem_vec *v, int block); /* device pointer */
+/* host <-> device copies of all blocks (host_blocks[b] has stfem_n_dofs doubles). Synchronous. */
+int stfem_vector_upload(stfem_vec *v, const double *const *host_blocks);
+int stfem_vector_download(const stfem_vec *v, double *const *host_blocks);
+
+/* SystemMatrix::vmult / Tvmult / vmult_slice / vmult_slice_add
+ * (include/operators.h:536-559, 561-583, 377-382, 586-611), fused into one cell sweep:
+ *   transpose == 0:  dst_j (+)= sum_i alpha[j*ncols+i] K src_i + beta[j*ncols+i] M src_i,
+ *                    j < nrows, i < ncols      (src has ncols blocks, dst has nrows)
+ *   transpose != 0:  dst_j (+)= sum_i alpha[i*ncols+j] K src_i + beta[i*ncols+j] M src_i,
+ *                    i < nrows, j < ncols      (src has nrows blocks, dst has ncols)
+ * alpha, beta: host, row-major nrows x ncols (FullMatrix<Number> Alpha, Beta).
+ * add == 0 overwrites dst (the reference's `dst = 0.0`), add != 0 accumulates
+ * (vmult_slice_add).  ncols == 1 is the reference's n x 1 "slice" case.
+ * K = MatrixFreeOperator(0,1), M = MatrixFreeOperator(1,0) with the coefficients set on ctx.
+ * Constrained rows of dst are left untouched (add) or zero (overwrite). */
+int stfem_st_vmult(stfem_ctx *ctx, int nrows, int ncols, const double *alpha, const double *beta,
+                   int transpose, int add, stfem_vec *dst, const stfem_vec *src, void *stream);
+
+/* MatrixFreeOperator::vmult (operators.h:1013-1018): dst = (ms*M_c + ls*K_c) src, one block. */
+int stfem_space_vmult(stfem_ctx *ctx, double mass_scaling, double laplace_scaling, stfem_vec *dst,
+                      const stfem_vec *src, void *stream);
+
+/* compute_diagonal / get_matrix_diagonal (operators.h:1092-1110, 1035-1039), forward diagonal
+ * of ms*M_c + ls*K_c into block 0 of diag; constrained rows are 0. */
+int stfem_diagonal(stfem_ctx *ctx, double mass_scaling, double laplace_scaling, stfem_vec *diag,
+                   void *stream);
+
+/* Block BLAS-1 used around the operator (operators.h:211-283 tensorproduct_add;
+ * LinearAlgebra::distributed::Vector::add / l2_norm / operator*).  Local to this rank:
+ * the caller all-reduces `out` over ranks (RCCL/MPI).  dot/norm are synchronous.
+ * n_own limits the reduction to the first n_own entries of every block (owned range). */
+int stfem_tensorproduct_add(stfem_ctx *ctx, int nrows, int ncols, const double *A, stfem_vec *c,
+                            const stfem_vec *b, void *stream);
+int stfem_dot(stfem_ctx *ctx, const stfem_vec *a, const stfem_vec *b, int64_t n_own, double *out,
+              void *stream);
+
+/* Halo support for z-slab partitions (deal.II: update_ghost_values / compress(add) inside
+ * MatrixFree::cell_loop, operators.h:1016-1017).  A rank's top DoF plane (iz = nz-1) is the
+ * ghost copy of its upper neighbour's bottom plane (iz = 0).
+ * pack:   buf[b*plane + i] = v_b[plane_index(iz) + i]        (plane = nx*ny doubles)
+ * unpack: v_b[plane_index(iz) + i]  = or +=  buf[b*plane + i]
+ * buf is a device pointer with n_blocks*nx*ny doubles. */
+int stfem_plane_pack(stfem_ctx *ctx, const stfem_vec *v, int iz, void *device_buf, void *stream);
+int stfem_plane_unpack(stfem_ctx *ctx, stfem_vec *v, int iz, const void *device_buf, int add,
+                       void *stream);
+
+/* Host-side helpers mirroring include/fe_time.h (type: 0 = CGP, 1 = DG).  Row-major outputs,
+ * nb = (type==0 ? r : r+1) * n_timesteps_at_once; returns nb or a negative status.
+ * get_fe_time_weights (fe_time.h:351-409) */
+int stfem_fe_time_weights(int type, int r, double time_step_size, int n_timesteps_at_once,
+                          double *Alpha, double *Beta, double *Gamma, double *Zeta);
+/* get_fe_time_weights_wave (fe_time.h:157-305) on the single-step matrices of the above */
+int stfem_fe_time_weights_wave(int type, int r, double time_step_size, int n_timesteps_at_once,
+                               double *Alpha_lhs, double *Beta_lhs, double *rhs_uK,
+                               double *rhs_uM, double *rhs_vM);
+/* Structured vertex grid with optional interior-vertex jitter (stand-in for
+ * GridTools::distort_random, tests/tp_01.cc:89-90; own mt19937_64 stream):
+ * out has (ncell+1)^3*3 doubles.  offset_cells/global_ncell select a z-slab of a global mesh
+ * so that all ranks see one consistent perturbation. */
+int stfem_mesh_vertices(const int32_t global_ncell[3], const double lower[3],
+                        const double upper[3], double distort, uint64_t seed, int32_t z_cell_begin,
+                        int32_t z_cell_end, double *out);
+/* Coefficient<dim>::value at cell centres (operators.h:870-965): one value per cell. */
+int stfem_coefficient_per_cell(const int32_t ncell[3], const double *vertices, double c1, double c2,
+                               double c3, double distort_coeff, const int32_t subdivisions[3],
+                               const double lower[3], const double upper[3], double *out);
+
+const char *stfem_strerror(int status);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char *stfem_last_hip_error(void);
+/* name of the kernel variant the last stfem_st_vmult on this ctx dispatched to (for profiles) */
+const char *stfem_last_kernel_name(const stfem_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STFEM_H */

@@ -1,0 +1,95 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/stfem.h
+declares, its host helpers agree with the oracle, and it fails loudly without a GPU."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def stfem():
+    mod = importlib.import_module("dealii-stfem_amd")
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    mod.lib()
+    return mod
+
+
+def test_header_symbols_exported(stfem):
+    text = open(stfem.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(stfem_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 25
+    raw = C.CDLL(stfem.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/stfem.h but not exported"
+    assert declared == set(stfem.SIGNATURES), declared ^ set(stfem.SIGNATURES)
+
+
+def test_time_weights_match_oracle(stfem, oracle_mod):
+    for t in (stfem.CGP, stfem.DG):
+        for r in range(1 if t == stfem.CGP else 0, 5):
+            for ns in (1, 2, 4):
+                got = stfem.get_fe_time_weights(t, r, 0.37, ns)
+                exp = oracle_mod.time_weights(t, r, 0.37, ns)
+                for g, e in zip(got, exp):
+                    np.testing.assert_allclose(g, e, rtol=0, atol=5e-13)
+                if r >= 1:
+                    got = stfem.get_fe_time_weights_wave(t, r, 0.37, ns)
+                    exp = oracle_mod.time_weights_wave(t, r, 0.37, ns)
+                    for g, e in zip(got, exp):
+                        np.testing.assert_allclose(g, e, rtol=1e-10, atol=1e-10)
+
+
+def test_time_weights_known_values(stfem):
+    A, B, G, Z = stfem.get_fe_time_weights(stfem.CGP, 2, 1.0, 1)
+    np.testing.assert_allclose(A, [[2 / 3, 0], [0, 1 / 6]], atol=1e-14)
+    np.testing.assert_allclose(B, [[4 / 3, 1 / 3], [-4 / 3, 2 / 3]], atol=1e-14)
+    A, B, G, Z = stfem.get_fe_time_weights(stfem.DG, 2, 1.0, 1)
+    np.testing.assert_allclose(np.diag(A), [.37640306, .51248583, 1 / 9], atol=1e-8)
+    np.testing.assert_allclose(G[:, 0], [1.5580782, -.89141154, 1 / 3], atol=1e-7)
+
+
+def test_bad_arguments_are_reported(stfem):
+    L = stfem.lib()
+    assert L.stfem_fe_time_weights(7, 1, 1.0, 1, None, None, None, None) < 0
+    assert L.stfem_ctx_create(None, None, None) == -1
+    assert b"invalid" in L.stfem_strerror(-1)
+
+
+def test_mesh_vertices(stfem):
+    gn = (4, 3, 6)
+    full = stfem.mesh_vertices(gn, (0, 0, 0), (1, 2, 3), distort=0.15, seed=5489)
+    assert full.shape == (5 * 4 * 7, 3)
+    # slabs of the same global mesh see the same perturbation
+    lo = stfem.mesh_vertices(gn, (0, 0, 0), (1, 2, 3), 0.15, 5489, z_range=(0, 2))
+    hi = stfem.mesh_vertices(gn, (0, 0, 0), (1, 2, 3), 0.15, 5489, z_range=(2, 6))
+    np.testing.assert_array_equal(lo, full[:5 * 4 * 3])
+    np.testing.assert_array_equal(hi, full[5 * 4 * 2:])
+    cart = stfem.mesh_vertices(gn, (0, 0, 0), (1, 2, 3))
+    d = (full - cart).reshape(7, 4, 5, 3)
+    assert np.all(d[0] == 0) and np.all(d[-1] == 0) and np.all(d[:, 0] == 0) and np.all(d[:, :, -1] == 0)
+    h = np.array([1 / 4, 2 / 3, 3 / 6])
+    assert np.all(np.abs(d) <= 0.15 * h + 1e-15) and np.abs(d[1:-1, 1:-1, 1:-1]).min() > 0
+
+
+def test_coefficient_per_cell_matches_oracle(stfem, oracle_mod):
+    nc = (10, 10, 5)
+    v = stfem.mesh_vertices(nc, (-1, -1, -1), (1, 1, 1))
+    got = stfem.coefficient_per_cell(nc, v, 1, 9, 16, 0.5, (5, 5, 5), (-1, -1, -1), (1, 1, 1))
+    orc = oracle_mod.Oracle(1, nc, v, 63)
+    exp = orc.coefficient_values(1, 9, 16, 0.5, (5, 5, 5), (-1, -1, -1), (1, 1, 1))
+    assert np.array_equal(exp.min(axis=1), exp.max(axis=1))  # constant per cell here
+    np.testing.assert_allclose(got, exp[:, 0], rtol=0, atol=0)
+
+
+def test_no_silent_cpu_fallback(stfem):
+    """Without a GPU the operator must refuse to construct (never route through the oracle)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(stfem.StfemError):
+        stfem.MatrixFreeOperator(2, (2, 2, 2))

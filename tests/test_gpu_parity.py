@@ -1,0 +1,193 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against
+ (a) the committed numpy golden fixtures and (b) the CPU oracle on seeded inputs.
+Tolerance: rel-L2 <= 1e-12 (BASELINE.json north_star: 'within 1e-12 rel-L2 of the CPU reference')."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def stfem():
+    mod = importlib.import_module("dealii-stfem_amd")
+    mod.lib()  # raises if the HIP library is missing: no fallback
+    return mod
+
+
+def apply(stfem, ctx, Alpha, Beta, X, transpose=False, add_to=None):
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    nsrc = Alpha.shape[0] if transpose else Alpha.shape[1]
+    ndst = Alpha.shape[1] if transpose else Alpha.shape[0]
+    src = stfem.BlockVector(ctx, nsrc).upload(X)
+    dst = stfem.BlockVector(ctx, ndst)
+    if add_to is not None:
+        dst.upload(add_to)
+        A._apply(dst, src, transpose, True, None)
+    elif transpose:
+        A.Tvmult(dst, src)
+    else:
+        A.vmult(dst, src)
+    return dst.download()
+
+
+CART_FIXTURES = ["q1_cart_3x3x3", "q2_cart_2x2x2", "q2_free_2x2x2", "q4_cart_2x2x2"]
+
+
+@pytest.mark.parametrize("name", CART_FIXTURES)
+def test_golden_fixture(name, stfem, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ctx = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                   dirichlet_mask=int(g["mask"]))
+    assert ctx.is_cartesian
+    assert ctx.n_dofs == g["X"].shape[1]
+    Y = apply(stfem, ctx, g["Alpha"], g["Beta"], g["X"])
+    assert rel(Y, g["Y"]) < TOL
+    YT = apply(stfem, ctx, g["Alpha"], g["Beta"], g["X"], transpose=True)
+    assert rel(YT, g["YT"]) < TOL
+    # MatrixFreeOperator::vmult, K = (0,1) and M = (1,0)
+    nb = g["X"].shape[0]
+    for ms, ls, ref in ((0.0, 1.0, g["KX"]), (1.0, 0.0, g["MX"])):
+        op = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                      dirichlet_mask=int(g["mask"]), mass_matrix_scaling=ms,
+                                      laplace_matrix_scaling=ls)
+        src = stfem.BlockVector(op, 1).upload(g["X"][:1])
+        dst = stfem.BlockVector(op, 1)
+        op.vmult(dst, src)
+        assert rel(dst.download(), ref[:1]) < TOL
+
+
+def random_blocks(n_blocks, n, seed=1234):
+    return np.stack([np.random.default_rng(seed + b).uniform(-1, 1, n) for b in range(n_blocks)])
+
+
+CASES = [
+    # p, ncell, lower, upper, mask, time type, r, nsteps, tau
+    (2, (16, 16, 16), (0, 0, 0), (1, 1, 1), 63, "CGP", 1, 4, 1 / 32),      # cfg 0 (tp_01 -d 3)
+    (4, (6, 5, 4), (0, 0, 0), (1, 1, 1), 63, "CGP", 2, 1, 1 / 144),        # cfg 1 small
+    (4, (7, 3, 2), (0, 0, 0), (2, 1, 0.5), 0, "CGP", 2, 2, 0.01),          # ragged, nb=4, no BC
+    (3, (5, 4, 6), (-1, -1, -1), (1, 1, 1), 63, "DG", 2, 1, 1 / 64),       # cfg 3 shape
+    (3, (3, 3, 3), (-1, -1, -1), (1, 1, 1), 0b010101, "DG", 1, 3, 0.1),    # nb=6
+    (1, (9, 7, 5), (0, 0, 0), (1, 1, 1), 63, "DG", 0, 1, 0.2),             # nb=1, Q1
+    (2, (4, 4, 3), (0, 0, 0), (1, 1, 1), 63, "CGP", 3, 4, 0.05),           # nb=12 -> tiled launches
+    (1, (1, 1, 1), (0, 0, 0), (1, 1, 1), 0, "CGP", 1, 1, 1.0),             # single cell
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"Q{c[0]}-{c[5]}{c[6]}x{c[7]}-{'x'.join(map(str, c[1]))}")
+def test_vs_oracle(case, stfem, oracle_mod):
+    p, nc, lo, up, mask, tt, r, ns, tau = case
+    t = stfem.CGP if tt == "CGP" else stfem.DG
+    Alpha, Beta, Gamma, Zeta = stfem.get_fe_time_weights(t, r, tau, ns)
+    verts = stfem.mesh_vertices(nc, lo, up)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts, dirichlet_mask=mask)
+    orc = oracle_mod.Oracle(p, nc, verts, mask)
+    nb = Alpha.shape[0]
+    X = random_blocks(nb, ctx.n_dofs)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    assert rel(apply(stfem, ctx, Alpha, Beta, X, transpose=True),
+               orc.st_vmult(Alpha, Beta, X, transpose=True)) < TOL
+    # vmult_slice / vmult_slice_add (rhs assembly, operators.h:377-382, 586-611)
+    g = Gamma if np.any(Gamma) else Zeta
+    z = Zeta if np.any(Zeta) else Gamma
+    ref = orc.st_vmult(g, z, X[:1])
+    got = apply(stfem, ctx, g, z, X[:1])
+    assert rel(got, ref) < TOL
+    got2 = apply(stfem, ctx, g, z, X[:1], add_to=ref)
+    assert rel(got2, 2 * ref) < TOL
+
+
+def test_wave_matrices_and_coefficient(stfem, oracle_mod):
+    """cfg 3 ingredients: Q3 x dG(2) wave matrices, c in {1,9,16} with per-coarse-cell factor."""
+    p, nc = 3, (10, 10, 5)
+    lo, up = (-1, -1, -1), (1, 1, 1)
+    A, B, _, _, _ = stfem.get_fe_time_weights_wave(stfem.DG, 2, 1 / 64, 1)
+    verts = stfem.mesh_vertices(nc, lo, up)
+    coef = stfem.coefficient_per_cell(nc, verts, 1, 9, 16, 0.5, (5, 5, 5), lo, up)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts)
+    ctx.evaluate_coefficient(coef, which=1)
+    orc = oracle_mod.Oracle(p, nc, verts, 63)
+    orc.set_coefficient(1, orc.coefficient_values(1, 9, 16, 0.5, (5, 5, 5), lo, up))
+    X = random_blocks(3, ctx.n_dofs)
+    assert rel(apply(stfem, ctx, A, B, X), orc.st_vmult(A, B, X)) < TOL
+    # mass coefficient too
+    cm = np.random.default_rng(5).uniform(0.5, 2.0, ctx.n_cells)
+    ctx.evaluate_coefficient(cm, which=0)
+    orc.set_coefficient(0, np.repeat(cm[:, None], (p + 1) ** 3, axis=1))
+    assert rel(apply(stfem, ctx, A, B, X), orc.st_vmult(A, B, X)) < TOL
+    ctx.evaluate_coefficient(None, which=0)
+    ctx.evaluate_coefficient(None, which=1)
+    orc.set_coefficient(0, None); orc.set_coefficient(1, None)
+    assert rel(apply(stfem, ctx, A, B, X), orc.st_vmult(A, B, X)) < TOL
+
+
+def test_rectangular_and_errors(stfem, oracle_mod):
+    p, nc = 2, (3, 4, 2)
+    verts = stfem.mesh_vertices(nc)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts)
+    orc = oracle_mod.Oracle(p, nc, verts, 63)
+    rng = np.random.default_rng(11)
+    Alpha = rng.uniform(-1, 1, (3, 2)); Beta = rng.uniform(-1, 1, (3, 2))
+    Alpha[1, 0] = 0.0
+    X = random_blocks(2, ctx.n_dofs)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    X3 = random_blocks(3, ctx.n_dofs)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X3, transpose=True),
+               orc.st_vmult(Alpha, Beta, X3, transpose=True)) < TOL
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    v2 = stfem.BlockVector(ctx, 2); v3 = stfem.BlockVector(ctx, 3)
+    with pytest.raises(stfem.StfemError) as e:
+        A.vmult(v2, v3)  # swapped block counts
+    assert e.value.status == -5
+    sq = stfem.SystemMatrix(ctx, np.eye(2), np.eye(2))
+    with pytest.raises(stfem.StfemError) as e:
+        sq.vmult(v2, v2)  # aliasing
+    assert e.value.status == -6
+    with pytest.raises(stfem.StfemError) as e:
+        stfem.MatrixFreeOperator(7, nc)
+    assert e.value.status == -2
+
+
+def test_linearity_and_constrained_rows(stfem):
+    """Size-independent properties at a larger size: linearity, Dirichlet rows stay zero,
+    and K annihilates constants on an unconstrained mesh."""
+    p, nc = 4, (12, 12, 12)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 1 / 144, 1)
+    ctx = stfem.MatrixFreeOperator(p, nc)
+    X = random_blocks(2, ctx.n_dofs); Y = random_blocks(2, ctx.n_dofs, seed=99)
+    AX = apply(stfem, ctx, Alpha, Beta, X); AY = apply(stfem, ctx, Alpha, Beta, Y)
+    AXY = apply(stfem, ctx, Alpha, Beta, 2.0 * X - 3.0 * Y)
+    assert rel(AXY, 2.0 * AX - 3.0 * AY) < 1e-13
+    n = p * nc[0] + 1
+    grid = AX.reshape(2, n, n, n)
+    for sl in (grid[:, 0], grid[:, -1], grid[:, :, 0], grid[:, :, -1], grid[:, :, :, 0], grid[:, :, :, -1]):
+        assert np.all(sl == 0.0)
+    free = stfem.MatrixFreeOperator(p, nc, dirichlet_mask=0, laplace_matrix_scaling=1.0)
+    one = stfem.BlockVector(free, 1).upload(np.ones((1, free.n_dofs)))
+    out = stfem.BlockVector(free, 1)
+    free.vmult(out, one)
+    assert np.abs(out.download()).max() < 1e-11
+    mass = stfem.MatrixFreeOperator(p, nc, dirichlet_mask=0, mass_matrix_scaling=1.0)
+    mass.vmult(out2 := stfem.BlockVector(mass, 1), stfem.BlockVector(mass, 1).upload(np.ones((1, mass.n_dofs))))
+    assert abs(out2.download().sum() - 1.0) < 1e-12
+
+
+def test_blas1_and_planes(stfem):
+    p, nc = 2, (3, 3, 3)
+    ctx = stfem.MatrixFreeOperator(p, nc)
+    n = ctx.n_dofs
+    X = random_blocks(3, n); Y = random_blocks(2, n, seed=7)
+    A = np.array([[1.5, 0.0, -2.0], [0.0, 0.25, 1.0]])
+    b = stfem.BlockVector(ctx, 3).upload(X); c = stfem.BlockVector(ctx, 2).upload(Y)
+    stfem.tensorproduct_add(ctx, c, A, b)
+    assert rel(c.download(), Y + A @ X) < 1e-15
+    assert abs(stfem.dot(ctx, b, b) - np.sum(X * X)) < 1e-10
+    plane = 7 * 7
+    assert abs(stfem.dot(ctx, b, b, n_own=n - plane) - np.sum(X[:, :n - plane] ** 2)) < 1e-10
