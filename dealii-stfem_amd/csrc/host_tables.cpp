@@ -241,6 +241,13 @@ ShapeTables make_shape_tables(int p)
   eo_pack(n, transpose(n, Si), t.eo_SiT);
   eo_pack(n, Dc, t.eo_Dc);
   eo_pack(n, transpose(n, Dc), t.eo_DcT);
+  {
+    Mat Lm(n * n, 0.0);
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b)
+        for (int q = 0; q < n; ++q) Lm[a * n + b] += Dc[q * n + a] * Dc[q * n + b];
+    eo_pack(n, Lm, t.eo_L);
+  }
   eo_pack(n, t.S, t.eo_S);
   eo_pack(n, transpose(n, t.S), t.eo_ST);
   eo_pack(n, t.Dcol, t.eo_Dq);

@@ -32,6 +32,7 @@ struct ShapeTables {
   Mat Dcol;      // plain collocation derivative on the Gauss points
   std::vector<double> xq, wq, nodes;
   double eo_Si[EO_MAX], eo_SiT[EO_MAX], eo_Dc[EO_MAX], eo_DcT[EO_MAX];
+  double eo_L[EO_MAX]; // L = Dc^T Dc: 1D weighted collocation Laplacian (symmetric type)
   double eo_S[EO_MAX], eo_ST[EO_MAX], eo_Dq[EO_MAX], eo_DqT[EO_MAX]; // unweighted S, Dcol
 };
 ShapeTables make_shape_tables(int p);

@@ -284,6 +284,7 @@ static void fill_common(const stfem_ctx *c, SweepParams &prm)
   std::memcpy(prm.eo_SiT, c->tab.eo_SiT, ne * sizeof(double));
   std::memcpy(prm.eo_Dc, c->tab.eo_Dc, ne * sizeof(double));
   std::memcpy(prm.eo_DcT, c->tab.eo_DcT, ne * sizeof(double));
+  std::memcpy(prm.eo_L, c->tab.eo_L, ne * sizeof(double));
 }
 
 // a(j,i), b(j,i): effective nbo x nbi matrices (row-major)

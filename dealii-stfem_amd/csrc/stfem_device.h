@@ -122,6 +122,41 @@ __device__ __forceinline__ void plane_laplace_inplace(const double *__restrict__
   }
 }
 
+// R += s * (X U) along one in-register direction (X of symmetric type)
+template <int N, bool ALONG_FAST>
+__device__ __forceinline__ void plane_sweep_acc(const double *__restrict__ c, double s,
+                                                const double (&U)[N * N], double (&R)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    double x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? U[o * N + i] : U[i * N + o];
+    eo_apply<N, +1>(c, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double &r = ALONG_FAST ? R[o * N + i] : R[i * N + o];
+      r = fma(s, y[i], r);
+    }
+  }
+}
+
+// P <- s * (X P) in place
+template <int N, bool ALONG_FAST>
+__device__ __forceinline__ void plane_sweep_scaled(const double *__restrict__ c, double s,
+                                                   double (&P)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    double x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
+    eo_apply<N, +1>(c, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) (ALONG_FAST ? P[o * N + i] : P[i * N + o]) = s * y[i];
+  }
+}
+
 // Orders the LDS traffic of ONE wave: everything this wave wrote before is visible to its
 // later reads.  No instruction is emitted beyond what the compiler needs for its own ordering.
 __device__ __forceinline__ void wave_lds_fence()
@@ -129,6 +164,18 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // also a scheduling barrier: without it the machine scheduler interleaves all five phases to
+  // hide LDS latency and needs > 256 VGPRs (1 wave/SIMD); phase-ordered code needs ~half
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Pins a register plane at this program point: everything that produces it is scheduled before,
+// everything that consumes it after.  (The DAG scheduler otherwise sinks whole sweeps next to
+// their far-away use and keeps three extra planes alive.)  Emits no instruction.
+template <int M> __device__ __forceinline__ void pin(double (&P)[M])
+{
+  STFEM_UNROLL
+  for (int e = 0; e < M; ++e) asm volatile("" : "+v"(P[e]));
 }
 
 } // namespace stfem

@@ -21,7 +21,7 @@ struct SweepParams {
   double ihx2, ihy2, ihz2;
   const double *coef_lap;  // per cell or nullptr
   const double *coef_mass; // per cell or nullptr
-  double eo_Si[EO_N], eo_SiT[EO_N], eo_Dc[EO_N], eo_DcT[EO_N];
+  double eo_Si[EO_N], eo_SiT[EO_N], eo_Dc[EO_N], eo_DcT[EO_N], eo_L[EO_N];
 };
 
 // Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.

@@ -6,11 +6,13 @@
 // around MatrixFreeOperator::do_cell_integral_local (operators.h:1135-1173), restructured:
 // the temporal combination commutes with the spatial interpolation, so it is applied once to
 // the x/y-interpolated data and the K and M parts share one evaluate/integrate pipeline
-// (13 one-dimensional sweeps per output block instead of 2 x 12 per input block).
+// (10 one-dimensional sweeps per output block instead of 2 x 12 per input block).
 #include "stfem_device.h"
 #include "stfem_kernels.h"
 
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 namespace stfem {
 
@@ -71,8 +73,10 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   }
   plane_sweep<N, +1, true>(prm.eo_Si, Ua);
   plane_sweep<N, +1, true>(prm.eo_Si, R);
-  plane_laplace_acc<N, true>(prm.eo_Dc, prm.eo_DcT, prm.ihz2, Ua, R);
-  plane_laplace_acc<N, false>(prm.eo_Dc, prm.eo_DcT, prm.ihy2, Ua, R);
+  // Cartesian cell, coefficient constant in the cell: D^T c D collapses to c * L (one sweep)
+  plane_sweep_acc<N, true>(prm.eo_L, prm.ihz2, Ua, R);
+  plane_sweep_acc<N, false>(prm.eo_L, prm.ihy2, Ua, R);
+  pin(R);
   wave_lds_fence();
   if (out_active) {
     STFEM_UNROLL
@@ -87,7 +91,7 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
   for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
-  plane_laplace_inplace<N, true>(prm.eo_Dc, prm.eo_DcT, prm.ihx2, PA);
+  plane_sweep_scaled<N, true>(prm.eo_L, prm.ihx2, PA);
   wave_lds_fence();
   if (out_active) {
     STFEM_UNROLL
@@ -142,7 +146,7 @@ template <int P> __device__ __forceinline__ bool constrained(const PlaneMask &m,
   return m.all || (x == 0 && m.x0) || (x == P && m.x1) || (y == 0 && m.y0) || (y == P && m.y1);
 }
 
-template <int P, int NBM>
+template <int P, int NBM, bool PLAIN_STORE>
 __global__ __launch_bounds__(256) void st_sweep_cart_atomic(const SweepParams prm)
 {
   using G = Geometry<P, NBM>;
@@ -202,7 +206,10 @@ __global__ __launch_bounds__(256) void st_sweep_cart_atomic(const SweepParams pr
     for (int y = 0; y < N; ++y)
       STFEM_UNROLL
     for (int x = 0; x < N; ++x)
-      if (!constrained<P>(pm, y, x)) unsafeAtomicAdd(d + int64_t(y) * prm.nx + x, PA[y * N + x]);
+      if (!constrained<P>(pm, y, x)) {
+        if (PLAIN_STORE) d[int64_t(y) * prm.nx + x] = PA[y * N + x]; // experiment only: wrong on shared DoFs
+        else unsafeAtomicAdd(d + int64_t(y) * prm.nx + x, PA[y * N + x]);
+      }
   }
 }
 
@@ -211,7 +218,11 @@ template <int P, int NBM> int launch_atomic_t(const SweepParams &prm, hipStream_
   using G = Geometry<P, NBM>;
   const int64_t cells_per_block = int64_t(G::CELLS_PER_WAVE) * G::WAVES;
   const int64_t blocks = (prm.ncells + cells_per_block - 1) / cells_per_block;
-  hipLaunchKernelGGL((st_sweep_cart_atomic<P, NBM>), dim3((unsigned)blocks), dim3(256), 0, st, prm);
+  static const bool plain = getenv("STFEM_EXPERIMENT_PLAIN_STORE") != nullptr;
+  if (plain)
+    hipLaunchKernelGGL((st_sweep_cart_atomic<P, NBM, true>), dim3((unsigned)blocks), dim3(256), 0, st, prm);
+  else
+    hipLaunchKernelGGL((st_sweep_cart_atomic<P, NBM, false>), dim3((unsigned)blocks), dim3(256), 0, st, prm);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
