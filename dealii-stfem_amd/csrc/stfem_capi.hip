@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,6 +46,10 @@ struct stfem_ctx {
   int coef_layout[2] = {0, 0};
   double *d_scratch = nullptr; // reductions
   const char *last_kernel = "";
+  // tile variant: halo slabs (grown on demand)
+  double *d_halo = nullptr;
+  size_t halo_doubles = 0;
+  int variant = 0; // 0 = tile (default), 1 = atomic
 };
 
 struct stfem_vec {
@@ -143,6 +148,7 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
     c->cartesian = cart;
     c->vertices.assign(v, v + 3 * nv);
   }
+  if (const char *v = getenv("STFEM_VARIANT")) c->variant = std::string(v) == "atomic" ? 1 : 0;
   if (hipMalloc(&c->d_scratch, 4096) != hipSuccess) {
     delete c;
     return STFEM_ERR_OUT_OF_MEMORY;
@@ -158,6 +164,7 @@ void stfem_ctx_destroy(stfem_ctx *c)
   for (double *&p : c->d_coef)
     if (p) (void)hipFree(p);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_halo) (void)hipFree(c->d_halo);
   delete c;
 }
 
@@ -287,6 +294,31 @@ static void fill_common(const stfem_ctx *c, SweepParams &prm)
   std::memcpy(prm.eo_L, c->tab.eo_L, ne * sizeof(double));
 }
 
+// Chooses the z-chunking of the tile variant: enough workgroups to fill 2 per CU several times
+// over, chunks long enough that the z-halo stays small.
+static void plan_chunks(const stfem_ctx *c, TilePlan &tp)
+{
+  tp.ntx = (c->nc[0] + tp.cw - 1) / tp.cw;
+  tp.nty = (c->nc[1] + tp.rows - 1) / tp.rows;
+  const int ncz = c->nc[2];
+  int lz;
+  if (const char *e = getenv("STFEM_TILE_LZ")) {
+    lz = std::max(1, std::min(ncz, atoi(e)));
+  } else {
+    const int64_t columns = int64_t(tp.ntx) * tp.nty, target = 4 * 512;
+    int ntc = int(std::max<int64_t>(1, std::min<int64_t>((target + columns / 2) / columns, std::max(1, ncz / 2))));
+    lz = (ncz + ntc - 1) / ntc;
+    // prefer a divisor of ncz nearby (equal chunks, no ragged tail)
+    for (int d = 0; d <= lz / 4; ++d) {
+      if (lz + d <= ncz && ncz % (lz + d) == 0) { lz += d; break; }
+      if (lz - d >= 1 && ncz % (lz - d) == 0) { lz -= d; break; }
+    }
+  }
+  tp.lz = lz;
+  tp.ntc = (ncz + lz - 1) / lz;
+  tp.zp = c->p * lz + 1;
+}
+
 // a(j,i), b(j,i): effective nbo x nbi matrices (row-major)
 static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,
                        const std::vector<double> &b, stfem_vec *dst, const stfem_vec *src, int add,
@@ -300,14 +332,16 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
   if (!c->cartesian) return STFEM_ERR_UNSUPPORTED;
   for (int w = 0; w < 2; ++w)
     if (c->coef_layout[w] == 2) return STFEM_ERR_UNSUPPORTED;
-  if (!add)
+  const bool atomic = c->variant == 1;
+  if (!add && atomic)
     for (int j = 0; j < nbo; ++j)
       HIP_TRY(hipMemsetAsync(dst->blk[j], 0, size_t(c->ndofs) * sizeof(double), st));
   SweepParams prm;
   fill_common(c, prm);
   prm.coef_lap = use_lap_coef ? c->d_coef[1] : nullptr;
   prm.coef_mass = use_mass_coef ? c->d_coef[0] : nullptr;
-  for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS)
+  for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS) {
+    bool first = true; // first launch into this row panel overwrites dst unless add
     for (int i0 = 0; i0 < nbi; i0 += MAX_BLOCKS) {
       const int tj = std::min(MAX_BLOCKS, nbo - j0), ti = std::min(MAX_BLOCKS, nbi - i0);
       bool nonzero = false;
@@ -317,16 +351,49 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
           prm.beta[j * ti + i] = b[size_t(j0 + j) * nbi + i0 + i];
           nonzero = nonzero || prm.alpha[j * ti + i] != 0.0 || prm.beta[j * ti + i] != 0.0;
         }
-      if (!nonzero) continue; // the reference skips exact zeros too (operators.h:551,556)
+      // the reference skips exact zeros too (operators.h:551,556); a panel may only be skipped
+      // if something else still defines dst
+      const bool last_panel = i0 + MAX_BLOCKS >= nbi;
+      if (!nonzero && (atomic || add || !first || !last_panel)) continue;
       prm.nbo = tj;
       prm.nbi = ti;
       for (int j = 0; j < tj; ++j) prm.dst[j] = dst->blk[j0 + j];
       for (int i = 0; i < ti; ++i) prm.src[i] = src->blk[i0 + i];
-      const int rc = launch_cart_atomic(c->p, prm, st);
+      int rc;
+      if (atomic) {
+        rc = launch_cart_atomic(c->p, prm, st);
+        c->last_kernel = cart_atomic_name(c->p, std::max(tj, ti));
+      } else {
+        TilePlan tp;
+        std::memset(&tp, 0, sizeof(tp));
+        const int nbm = std::max(tj, ti);
+        if (tile_geometry(c->p, nbm, tp) != 0) return STFEM_ERR_UNSUPPORTED;
+        plan_chunks(c, tp);
+        const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
+        const size_t ntiles = size_t(tp.ntx) * tp.nty * tp.ntc;
+        const size_t nxh = ntiles * nbm_r * tp.zp * tp.tY, nyh = ntiles * nbm_r * tp.zp * tp.tX,
+                     nzh = ntiles * nbm_r * tp.tY * tp.tX;
+        if (nxh + nyh + nzh > c->halo_doubles) {
+          HIP_TRY(hipStreamSynchronize(st));
+          if (c->d_halo) HIP_TRY(hipFree(c->d_halo));
+          c->d_halo = nullptr;
+          c->halo_doubles = 0;
+          if (hipMalloc(&c->d_halo, (nxh + nyh + nzh) * sizeof(double)) != hipSuccess)
+            return STFEM_ERR_OUT_OF_MEMORY;
+          c->halo_doubles = nxh + nyh + nzh;
+        }
+        tp.xh = c->d_halo;
+        tp.yh = c->d_halo + nxh;
+        tp.zh = c->d_halo + nxh + nyh;
+        tp.add = (add || !first) ? 1 : 0;
+        rc = launch_cart_tile(c->p, prm, tp, st);
+        c->last_kernel = cart_tile_name(c->p, nbm);
+      }
       if (rc == -3) return hip_fail(hipGetLastError(), "kernel launch");
       if (rc != 0) return STFEM_ERR_UNSUPPORTED;
-      c->last_kernel = cart_atomic_name(c->p, std::max(tj, ti));
+      first = false;
     }
+  }
   return STFEM_OK;
 }
 

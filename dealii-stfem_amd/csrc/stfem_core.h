@@ -1,0 +1,150 @@
+// Shared device code of the fused space-time cell sweep: wave geometry, the per-cell core
+// (evaluate -> temporal combination -> quadrature-space operator -> integrate) and the
+// Dirichlet masks.  Included by stfem_kernels.hip (atomic variant) and stfem_tile.hip.
+//
+// The core computes, for every cell and all temporal blocks at once,
+//     out_j = sum_i alpha(j,i) K_cell u_i + beta(j,i) M_cell u_i
+// i.e. the per-cell body of SystemMatrix::vmult (reference include/operators.h:536-559) around
+// MatrixFreeOperator::do_cell_integral_local (operators.h:1135-1173), restructured: the temporal
+// combination commutes with the spatial interpolation, so it is applied once to the
+// x/y-interpolated data and the K and M parts share one evaluate/integrate pipeline
+// (10 one-dimensional sweeps per output block instead of 2 x 12 per input block).
+#pragma once
+#include "stfem_device.h"
+#include "stfem_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace stfem {
+
+template <int P, int NBM> struct Geometry {
+  static constexpr int N = P + 1;
+  static constexpr int CB_PER_WAVE = 64 / N;            // cell-blocks (cell x temporal block) per wave
+  static constexpr int CELLS_PER_WAVE = CB_PER_WAVE / NBM;
+  static constexpr int ACTIVE = CELLS_PER_WAVE * NBM * N; // active lanes
+  static constexpr int CBS = N * N * N;                   // LDS doubles per cell-block
+  static constexpr int WAVES = 4;
+  static constexpr int LDS_PER_WAVE = CELLS_PER_WAVE * NBM * CBS;
+};
+
+// One pass of the fused operator over the cells owned by this wave.
+// PA: on entry the nodal src plane (layout A, [y][x]) of (cell, input block blk, z-plane k),
+//     on exit the nodal result plane of (cell, output block blk, z-plane k).
+template <int P, int NBM>
+__device__ __forceinline__ void
+cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, int blk, int k,
+          bool in_active, bool out_active, const double (&aK)[NBM], const double (&aM)[NBM],
+          double (&PA)[(P + 1) * (P + 1)])
+{
+  using G = Geometry<P, NBM>;
+  constexpr int N = G::N;
+  constexpr int CBS = G::CBS;
+  double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+
+  // ---- phase A: interpolate x, y (registers), hand over to layout B
+  plane_sweep<N, +1, true>(prm.eo_Si, PA);
+  plane_sweep<N, +1, false>(prm.eo_Si, PA);
+  if (in_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int x = 0; x < N; ++x) cb_lds[k * N * N + y * N + x] = PA[y * N + x];
+  }
+  wave_lds_fence();
+
+  // ---- phase B: temporal combination, interpolate z, mass + y/z Laplacian
+  double Ua[N * N], R[N * N];
+  STFEM_UNROLL
+  for (int e = 0; e < N * N; ++e) Ua[e] = R[e] = 0.0;
+  STFEM_UNROLL
+  for (int i = 0; i < NBM; ++i) {
+    if (i < prm.nbi) {
+      const double *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
+      STFEM_UNROLL
+      for (int y = 0; y < N; ++y)
+        STFEM_UNROLL
+      for (int z = 0; z < N; ++z) {
+        const double v = in_lds[z * N * N + y * N + k];
+        Ua[y * N + z] = fma(aK[i], v, Ua[y * N + z]);
+        R[y * N + z] = fma(aM[i], v, R[y * N + z]);
+      }
+    }
+  }
+  plane_sweep<N, +1, true>(prm.eo_Si, Ua);
+  plane_sweep<N, +1, true>(prm.eo_Si, R);
+  // Cartesian cell, coefficient constant in the cell: D^T c D collapses to c * L (one sweep)
+  plane_sweep_acc<N, true>(prm.eo_L, prm.ihz2, Ua, R);
+  plane_sweep_acc<N, false>(prm.eo_L, prm.ihy2, Ua, R);
+  pin(R);
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int z = 0; z < N; ++z) cb_lds[z * N * N + y * N + k] = Ua[y * N + z];
+  }
+  wave_lds_fence();
+
+  // ---- phase A2: x Laplacian in layout A
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  plane_sweep_scaled<N, true>(prm.eo_L, prm.ihx2, PA);
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int x = 0; x < N; ++x) cb_lds[k * N * N + y * N + x] = PA[y * N + x];
+  }
+  wave_lds_fence();
+
+  // ---- phase B2: collect, integrate z
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int z = 0; z < N; ++z) R[y * N + z] += cb_lds[z * N * N + y * N + k];
+  plane_sweep<N, +1, true>(prm.eo_SiT, R);
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int z = 0; z < N; ++z) cb_lds[z * N * N + y * N + k] = R[y * N + z];
+  }
+  wave_lds_fence();
+
+  // ---- phase A3: integrate y, x
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  plane_sweep<N, +1, false>(prm.eo_SiT, PA);
+  plane_sweep<N, +1, true>(prm.eo_SiT, PA);
+  wave_lds_fence();
+}
+
+// Dirichlet flags of the plane (cell, k): which local rows/columns are constrained.
+struct PlaneMask {
+  bool x0, x1, y0, y1, all;
+};
+template <int P>
+__device__ __forceinline__ PlaneMask plane_mask(const SweepParams &prm, int cx, int cy, int cz, int k)
+{
+  PlaneMask m;
+  m.x0 = (prm.dmask & 1) && cx == 0;
+  m.x1 = (prm.dmask & 2) && cx == prm.ncx - 1;
+  m.y0 = (prm.dmask & 4) && cy == 0;
+  m.y1 = (prm.dmask & 8) && cy == prm.ncy - 1;
+  m.all = ((prm.dmask & 16) && cz == 0 && k == 0) || ((prm.dmask & 32) && cz == prm.ncz - 1 && k == P);
+  return m;
+}
+template <int P> __device__ __forceinline__ bool constrained(const PlaneMask &m, int y, int x)
+{
+  return m.all || (x == 0 && m.x0) || (x == P && m.x1) || (y == 0 && m.y0) || (y == P && m.y1);
+}
+
+constexpr int round_nbm(int nbm) { return nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8); }
+
+} // namespace stfem

@@ -24,10 +24,28 @@ struct SweepParams {
   double eo_Si[EO_N], eo_SiT[EO_N], eo_Dc[EO_N], eo_DcT[EO_N], eo_L[EO_N];
 };
 
+// Decomposition used by the "tile" variant: a workgroup owns a tile of cw x rows cells in x-y and
+// marches through lz cell layers in z, accumulating shared DoFs in LDS.  Partial sums on the
+// tile's upper x/y/z faces go to per-tile halo slabs and are added to their owner by a small
+// fix-up kernel, so no global atomics and no zeroing of dst are needed.
+struct TilePlan {
+  int cw, rows;      // cells per wave along x, waves (= cell rows along y) per tile
+  int ntx, nty, ntc; // tiles in x, y and chunks in z
+  int lz;            // cell layers per chunk (the last chunk may have fewer)
+  int tX, tY, zp;    // slab extents: P*cw+1, P*rows+1, P*lz+1
+  double *xh, *yh, *zh; // halo slabs [tile][block][...]
+  int add;           // accumulate into dst instead of overwriting
+};
+
 // Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.
 // Variant "atomic": result scattered with global fp64 atomics into a pre-zeroed dst.
 // Returns 0, or -2 if (p, nbm) has no instantiation.
 int launch_cart_atomic(int p, const SweepParams &prm, void *stream);
 const char *cart_atomic_name(int p, int nbm);
+
+// Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm); returns 0 or -2.
+int tile_geometry(int p, int nbm, TilePlan &plan);
+int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);
+const char *cart_tile_name(int p, int nbm);
 
 } // namespace stfem
