@@ -288,9 +288,6 @@ static void fill_common(const stfem_ctx *c, SweepParams &prm)
   prm.ihz2 = 1.0 / (c->h[2] * c->h[2]);
   const int ne = eo_size(c->p + 1);
   std::memcpy(prm.eo_Si, c->tab.eo_Si, ne * sizeof(double));
-  std::memcpy(prm.eo_SiT, c->tab.eo_SiT, ne * sizeof(double));
-  std::memcpy(prm.eo_Dc, c->tab.eo_Dc, ne * sizeof(double));
-  std::memcpy(prm.eo_DcT, c->tab.eo_DcT, ne * sizeof(double));
   std::memcpy(prm.eo_L, c->tab.eo_L, ne * sizeof(double));
 }
 
@@ -371,20 +368,21 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
         plan_chunks(c, tp);
         const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
         const size_t ntiles = size_t(tp.ntx) * tp.nty * tp.ntc;
-        const size_t nxh = ntiles * nbm_r * tp.zp * tp.tY, nyh = ntiles * nbm_r * tp.zp * tp.tX,
-                     nzh = ntiles * nbm_r * tp.tY * tp.tX;
-        if (nxh + nyh + nzh > c->halo_doubles) {
+        const size_t nyh = ntiles * nbm_r * tp.zp * tp.tX, nzh = ntiles * nbm_r * tp.tY * tp.tX,
+                     nxs = ntiles * nbm_r * tp.zp * tp.tY;
+        if (nyh + nzh + 2 * nxs > c->halo_doubles) {
           HIP_TRY(hipStreamSynchronize(st));
           if (c->d_halo) HIP_TRY(hipFree(c->d_halo));
           c->d_halo = nullptr;
           c->halo_doubles = 0;
-          if (hipMalloc(&c->d_halo, (nxh + nyh + nzh) * sizeof(double)) != hipSuccess)
+          if (hipMalloc(&c->d_halo, (nyh + nzh + 2 * nxs) * sizeof(double)) != hipSuccess)
             return STFEM_ERR_OUT_OF_MEMORY;
-          c->halo_doubles = nxh + nyh + nzh;
+          c->halo_doubles = nyh + nzh + 2 * nxs;
         }
-        tp.xh = c->d_halo;
-        tp.yh = c->d_halo + nxh;
-        tp.zh = c->d_halo + nxh + nyh;
+        tp.yh = c->d_halo;
+        tp.zh = c->d_halo + nyh;
+        tp.xl = tp.zh + nzh;
+        tp.xr = tp.xl + nxs;
         tp.add = (add || !first) ? 1 : 0;
         rc = launch_cart_tile(c->p, prm, tp, st);
         c->last_kernel = cart_tile_name(c->p, nbm);

@@ -105,7 +105,7 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
   for (int z = 0; z < N; ++z) R[y * N + z] += cb_lds[z * N * N + y * N + k];
-  plane_sweep<N, +1, true>(prm.eo_SiT, R);
+  plane_sweep_T<N, true>(prm.eo_Si, R);
   wave_lds_fence();
   if (out_active) {
     STFEM_UNROLL
@@ -120,8 +120,8 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
   for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
-  plane_sweep<N, +1, false>(prm.eo_SiT, PA);
-  plane_sweep<N, +1, true>(prm.eo_SiT, PA);
+  plane_sweep_T<N, false>(prm.eo_Si, PA);
+  plane_sweep_T<N, true>(prm.eo_Si, PA);
   wave_lds_fence();
 }
 

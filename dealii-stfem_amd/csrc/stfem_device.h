@@ -65,6 +65,56 @@ __device__ __forceinline__ void eo_apply(const double *__restrict__ c, const dou
   }
 }
 
+// y = X^T x for a symmetric-type X packed in c (the transpose has the same constants:
+// ee^T[q][i] = ee[i][q], oo^T[q][i] = oo[i][q], em <-> mm), so S and S^T share their SGPRs.
+template <int N>
+__device__ __forceinline__ void eo_apply_T(const double *__restrict__ c, const double (&x)[N],
+                                           double (&y)[N])
+{
+  constexpr int H = N / 2;
+  constexpr bool ODD = (N & 1) != 0;
+  double xe[H > 0 ? H : 1], xo[H > 0 ? H : 1];
+  STFEM_UNROLL
+  for (int i = 0; i < H; ++i) {
+    xe[i] = x[i] + x[N - 1 - i];
+    xo[i] = x[i] - x[N - 1 - i];
+  }
+  STFEM_UNROLL
+  for (int q = 0; q < H; ++q) {
+    double a = c[q] * xe[0];
+    double b = c[H * H + q] * xo[0];
+    STFEM_UNROLL
+    for (int i = 1; i < H; ++i) {
+      a = fma(c[i * H + q], xe[i], a);
+      b = fma(c[H * H + i * H + q], xo[i], b);
+    }
+    if (ODD) a = fma(c[2 * H * H + H + q], x[H], a); // em^T = mm
+    y[q] = a + b;
+    y[N - 1 - q] = a - b;
+  }
+  if (ODD) {
+    double m = c[2 * H * H + 2 * H] * x[H];
+    STFEM_UNROLL
+    for (int i = 0; i < H; ++i) m = fma(c[2 * H * H + i], xe[i], m); // mm^T = em
+    y[H] = m;
+  }
+}
+
+// In-place sweep with the transposed matrix
+template <int N, bool ALONG_FAST>
+__device__ __forceinline__ void plane_sweep_T(const double *__restrict__ c, double (&P)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    double x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
+    eo_apply_T<N>(c, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) (ALONG_FAST ? P[o * N + i] : P[i * N + o]) = y[i];
+  }
+}
+
 // In-place sweep over an N x N register plane P[s*N + f] (s slow, f fast index).
 // ALONG_FAST: contract the fast index for every slow index; else contract the slow index.
 template <int N, int SIGN, bool ALONG_FAST>

@@ -21,20 +21,23 @@ struct SweepParams {
   double ihx2, ihy2, ihz2;
   const double *coef_lap;  // per cell or nullptr
   const double *coef_mass; // per cell or nullptr
-  double eo_Si[EO_N], eo_SiT[EO_N], eo_Dc[EO_N], eo_DcT[EO_N], eo_L[EO_N];
+  double eo_Si[EO_N], eo_L[EO_N]; // even-odd packed: interpolation (weights folded), 1D Laplacian
 };
 
 // Decomposition used by the "tile" variant: a workgroup owns a tile of cw x rows cells in x-y and
-// marches through lz cell layers in z, accumulating shared DoFs in LDS.  Partial sums on the
-// tile's upper x/y/z faces go to per-tile halo slabs and are added to their owner by a small
-// fix-up kernel, so no global atomics and no zeroing of dst are needed.
+// marches through lz cell layers in z, accumulating shared DoFs in LDS.  x-neighbouring tiles
+// are launched in two colours (odd tiles read-modify-write the shared columns); partial sums on
+// a tile's upper y/z faces go to per-tile halo slabs and are added to their owner by a small
+// fix-up kernel.  No global atomics and no zeroing of dst are needed.
 struct TilePlan {
   int cw, rows;      // cells per wave along x, waves (= cell rows along y) per tile
   int ntx, nty, ntc; // tiles in x, y and chunks in z
   int lz;            // cell layers per chunk (the last chunk may have fewer)
   int tX, tY, zp;    // slab extents: P*cw+1, P*rows+1, P*lz+1
-  double *xh, *yh, *zh; // halo slabs [tile][block][...]
+  double *yh, *zh;   // halo slabs: yh[tile][block][zl][X], zh[tile][block][Y][X]
+  double *xl, *xr;   // x-face slabs of odd tiles: [tile][block][zl][Y] (their X = 0 / X = xext columns)
   int add;           // accumulate into dst instead of overwriting
+  int xcolor;        // parity of the tile x-index handled by this launch
 };
 
 // Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.

@@ -3,17 +3,22 @@
 // A 256-thread workgroup (4 waves) owns a tile of CW x 4 cells in x-y (one wave per cell row)
 // and marches through LZ cell layers in z:
 //
-//   per layer:  gather src planes from HBM (coalesced along x, faces shared through L1/L2)
+//   per layer:  gather src planes from HBM (5 contiguous doubles per row, faces shared through
+//               L1/L2; the next layer is prefetched into registers during the compute)
 //               -> cell_core (registers + wave-private LDS transposes)
 //               -> accumulate the (p+1)^3 results of all cells of the layer in an LDS slab
 //                  (owner lane writes, the other sharers ds_add_f64)
-//               -> stream the four finished DoF planes of the layer to HBM, rows of
-//                  p*CW+1 contiguous doubles; the fifth plane is carried to the next layer.
+//               -> stream the finished DoF planes of the layer to HBM as rows of p*CW+1
+//                  contiguous doubles; the top plane is carried to the next layer in LDS.
 //
-// DoFs on the tile's upper x / y / z face belong to the neighbouring tile: their partial sums are
-// written (plain stores) to per-tile halo slabs and added to the owner's value by
-// st_tile_fixup.  Every DoF of dst is therefore written exactly once by plain stores: no global
-// atomics, no memset, bit-reproducible results up to the order of the LDS adds.
+// Shared DoFs between tiles:
+//   x faces: tiles are 2-coloured by the parity of their x index; odd tiles run first and put
+//            their partial sums of the two shared columns into contiguous x-slabs; even tiles
+//            run second, prefetch the neighbours' slabs at the start of a layer, add them into
+//            the LDS slab and store complete rows (no strided plane access, no RMW of dst);
+//   y/z faces: partial sums of a tile's upper y / z face go to per-tile halo slabs (plain,
+//            contiguous stores) and are added to the owner's rows by st_tile_fixup.
+// Every DoF of dst is written by plain stores: no global atomics, no memset of dst.
 //
 // Replaces the scatter of MatrixFreeOperator::do_cell_integral_range
 // (reference include/operators.h:1112-1133, distribute_local_to_global) and the dst = 0 /
@@ -32,26 +37,26 @@ template <int P, int NBM> struct TileGeom {
   static constexpr int TX = P * CW + 1;
   static constexpr int TY = P * ROWS + 1;
   static constexpr int PLANE = TX * TY;
-  static constexpr int ACC = NBM * N * PLANE;                 // accumulation slab (aliases trans)
-  static constexpr int TRANS = G::WAVES * G::LDS_PER_WAVE;    // transpose slabs
+  static constexpr int ACC = NBM * N * PLANE;              // accumulation slab (aliases trans)
+  static constexpr int TRANS = G::WAVES * G::LDS_PER_WAVE; // transpose slabs
   static constexpr int MAIN = ACC > TRANS ? ACC : TRANS;
   static constexpr int CARRY = NBM * PLANE;
   static constexpr int LDS_DOUBLES = MAIN + CARRY;
 };
 
 struct TileCoords {
-  int tx, ty, tc;          // tile indices
-  int cx0, cy0, cz0;       // first cell
-  int ncx, ncy, nlay;      // active cells / layers in this tile
+  int tx, ty, tc;     // tile indices
+  int cx0, cy0, cz0;  // first cell
+  int ncx, ncy, nlay; // active cells / layers in this tile
   bool last_x, last_y, last_z;
 };
 
-__device__ __forceinline__ TileCoords tile_coords(const SweepParams &prm, const TilePlan &tp, int id)
+__device__ __forceinline__ TileCoords tile_coords(const SweepParams &prm, const TilePlan &tp, int tx, int ty, int tc)
 {
   TileCoords t;
-  t.tx = id % tp.ntx;
-  t.ty = (id / tp.ntx) % tp.nty;
-  t.tc = id / (tp.ntx * tp.nty);
+  t.tx = tx;
+  t.ty = ty;
+  t.tc = tc;
   t.cx0 = t.tx * tp.cw;
   t.cy0 = t.ty * tp.rows;
   t.cz0 = t.tc * tp.lz;
@@ -70,9 +75,17 @@ __device__ __forceinline__ int logical_block(int b, int nblocks)
 {
   const int per = nblocks / 8, rem = nblocks % 8;
   const int xcd = b % 8, slot = b / 8;
-  // XCDs 0..rem-1 hold per+1 tiles
-  const int start = xcd * per + min(xcd, rem);
-  return start + slot;
+  return xcd * per + min(xcd, rem) + slot;
+}
+
+template <int P>
+__device__ __forceinline__ void load_plane(const double *__restrict__ s, int nx, double (&PA)[(P + 1) * (P + 1)])
+{
+  constexpr int N = P + 1;
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int x = 0; x < N; ++x) PA[y * N + x] = s[int64_t(y) * nx + x];
 }
 
 template <int P, int NBM>
@@ -91,8 +104,13 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
   const int wave = tid >> 6;
   double *lds = smem + wave * G::LDS_PER_WAVE;
 
-  const int nblocks = tp.ntx * tp.nty * tp.ntc;
-  const TileCoords t = tile_coords(prm, tp, logical_block(blockIdx.x, nblocks));
+  // tiles of this launch's x colour
+  const int ntxh = (tp.ntx - tp.xcolor + 1) / 2;
+  const int nblocks = ntxh * tp.nty * tp.ntc;
+  const int id = logical_block(blockIdx.x, nblocks);
+  const TileCoords t =
+    tile_coords(prm, tp, 2 * (id % ntxh) + tp.xcolor, (id / ntxh) % tp.nty, id / (ntxh * tp.nty));
+  const int tile_id = t.tx + tp.ntx * (t.ty + tp.nty * t.tc);
 
   const bool lane_ok = lane < G::ACTIVE;
   const int l = lane_ok ? lane : 0;
@@ -119,27 +137,57 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
   const bool own_x_hi = cxl == t.ncx - 1; // last active cell of the row owns its x = P column
   const bool own_y_hi = cyl == t.ncy - 1;
 
+  // Dirichlet rows only matter for tiles that touch the domain boundary (uniform test)
+  const bool xy_boundary = ((prm.dmask & 1) && t.tx == 0) || ((prm.dmask & 2) && t.last_x) ||
+                           ((prm.dmask & 4) && t.ty == 0) || ((prm.dmask & 8) && t.last_y);
+
   for (int e = tid; e < TG::CARRY; e += 256) carry[e] = 0.0;
   __syncthreads();
 
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
   const int64_t xy_base = int64_t(P) * cx + int64_t(prm.nx) * (int64_t(P) * cy);
-  const double *src_blk = prm.src[in_active ? blk : 0];
+  // lanes that feed nothing still load from a valid address; their planes are never used
+  const double *src_lane = prm.src[in_active ? blk : 0] + xy_base + plane_stride * k;
+  double *a = acc + ((blk * N + k) * TY + P * cyl) * TX + P * cxl;
+
+  // store phase: one row of the slab per half-wave (32 lanes, X = lane within the half)
+  const int hw = 2 * wave + (lane >> 5), X = lane & 31;
+  const int xext = P * t.ncx, yext = P * t.ncy;
+  const bool x_lane = X <= xext;
+  const int ymax = t.last_y ? yext + 1 : yext; // rows [0, ymax) go to dst, row yext to yh otherwise
+  // x faces: odd tiles divert their shared columns to the x-slabs, even tiles collect them
+  const bool odd = tp.xcolor == 1;
+  const bool divert_lane = odd && (X == 0 || (X == xext && !t.last_x));
+  double *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
+  const bool collect_left = !odd && t.tx > 0, collect_right = !odd && !t.last_x;
+  constexpr int XE = (2 * NBM * N * TY + 255) / 256; // slab values per thread and layer
+  const int nrows = prm.nbo * N * TY;
+  const int64_t tile_goff = int64_t(P) * t.cx0 + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
+                            plane_stride * (int64_t(P) * t.cz0);
+  const int lane_goff = X + prm.nx * hw, lane_aoff = hw * TX + X;
+
+  double PN[N * N];
+  load_plane<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PN);
 
   for (int layer = 0; layer < t.nlay; ++layer) {
     const int cz = t.cz0 + layer;
+    const bool last_layer = layer == t.nlay - 1;
+    const bool z_boundary = ((prm.dmask & 16) && cz == 0) || ((prm.dmask & 32) && cz == prm.ncz - 1);
+    const bool masked = xy_boundary || z_boundary;
     PlaneMask pm = plane_mask<P>(prm, cx, cy, cz, k);
     double PA[N * N];
-    {
-      const double *s = src_blk + xy_base + plane_stride * (int64_t(P) * cz + k);
+    STFEM_UNROLL
+    for (int e = 0; e < N * N; ++e) PA[e] = PN[e];
+    if (masked) {
       STFEM_UNROLL
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
-      for (int x = 0; x < N; ++x) {
-        const double v = in_active ? s[int64_t(y) * prm.nx + x] : 0.0;
-        PA[y * N + x] = constrained<P>(pm, y, x) ? 0.0 : v;
-      }
+      for (int x = 0; x < N; ++x)
+        if (constrained<P>(pm, y, x)) PA[y * N + x] = 0.0;
     }
+    // prefetch the next layer's plane while this one is being processed
+    if (!last_layer) load_plane<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PN);
+
     double aK[NBM], aM[NBM];
     {
       const int64_t c = cell_xy + cells_per_layer * cz;
@@ -152,127 +200,171 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
       }
     }
 
-    cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
-
-    __syncthreads(); // all waves are done with the transpose slabs: the region becomes `acc`
-
-    // owner lanes initialise their DoFs (adding the plane carried from the previous layer)
-    double *a = acc + ((blk * N + k) * TY + P * cyl) * TX + P * cxl;
-    const double *cr = carry + (blk * TY + P * cyl) * TX + P * cxl;
-    if (out_active) {
+    // even tiles: fetch the odd neighbours' partial sums of the shared columns for this layer
+    // (issued before the compute, consumed after it)
+    double xe[XE];
+    int xe_idx[XE];
+    STFEM_UNROLL
+    for (int m = 0; m < XE; ++m) {
+      xe[m] = 0.0;
+      xe_idx[m] = -1;
+    }
+    if (collect_left || collect_right) {
       STFEM_UNROLL
-      for (int y = 0; y < N; ++y)
-        STFEM_UNROLL
-      for (int x = 0; x < N; ++x) {
-        const bool owned = (x < P || own_x_hi) && (y < P || own_y_hi);
-        if (owned) {
-          double v = constrained<P>(pm, y, x) ? 0.0 : PA[y * N + x];
-          if (k == 0) v += cr[y * TX + x];
-          a[y * TX + x] = v;
+      for (int m = 0; m < XE; ++m) {
+        const int e = tid + 256 * m;
+        const int side = e >= nrows ? 1 : 0, row = e - side * nrows;
+        const int Y = row % TY, jk = row / TY, kk = jk % N, j = jk / N;
+        const bool to_dst = Y < ymax && (kk < P || (last_layer && t.last_z));
+        if (e < 2 * nrows && to_dst && (side == 0 ? collect_left : collect_right)) {
+          const int nid = tile_id + (side == 0 ? -1 : 1);
+          const double *slab = (side == 0 ? tp.xr : tp.xl) + int64_t(nid) * NBM * tp.zp * tp.tY;
+          xe[m] = slab[(j * tp.zp + P * layer + kk) * tp.tY + Y];
+          xe_idx[m] = row * TX + (side == 0 ? 0 : xext);
         }
       }
     }
-    __syncthreads();
-    // the other sharers of a face / edge / vertex DoF add their part
+
+    cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
+
+    if (masked) {
+      STFEM_UNROLL
+      for (int y = 0; y < N; ++y)
+        STFEM_UNROLL
+      for (int x = 0; x < N; ++x)
+        if (constrained<P>(pm, y, x)) PA[y * N + x] = 0.0;
+    }
+
+    __syncthreads(); // all waves are done with the transpose slabs: the region becomes `acc`
+
+    // owner lanes initialise their DoFs
     if (out_active) {
       STFEM_UNROLL
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
       for (int x = 0; x < N; ++x) {
         const bool owned = (x < P || own_x_hi) && (y < P || own_y_hi);
-        if ((x == P || y == P) && !owned && !constrained<P>(pm, y, x))
-          atomicAdd(&a[y * TX + x], PA[y * N + x]); // ds_add_f64
+        if (owned) a[y * TX + x] = PA[y * N + x];
       }
     }
     __syncthreads();
-
-    // stream the finished planes k = 0..P-1 (and k = P on the last layer) to their destination
-    const bool last_layer = layer == t.nlay - 1;
-    const int xext = P * t.ncx, yext = P * t.ncy; // highest local index in use
-    for (int e = tid; e < NBM * N * PLANE; e += 256) {
-      const int X = e % TX, r = e / TX;
-      const int Y = r % TY, kk = (r / TY) % N, j = r / (TY * N);
-      if (j >= prm.nbo || X > xext || Y > yext) continue;
-      const double v = acc[e];
-      if (kk == P && !last_layer) {
-        carry[(j * TY + Y) * TX + X] = v;
-        continue;
-      }
-      const int zl = P * layer + kk; // chunk-local plane
-      const int tile_id = t.tx + tp.ntx * (t.ty + tp.nty * t.tc);
-      if (X == xext && !t.last_x) {
-        tp.xh[((int64_t(tile_id) * NBM + j) * tp.zp + zl) * tp.tY + Y] = v;
-      } else if (Y == yext && !t.last_y) {
-        tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + zl) * tp.tX + X] = v;
-      } else if (kk == P && !t.last_z) { // only on the last layer
-        tp.zh[((int64_t(tile_id) * NBM + j) * tp.tY + Y) * tp.tX + X] = v;
-      } else {
-        const int64_t g = int64_t(P) * t.cx0 + X + int64_t(prm.nx) * (int64_t(P) * t.cy0 + Y) +
-                          plane_stride * (int64_t(P) * t.cz0 + zl);
-        double *d = prm.dst[j] + g;
-        *d = tp.add ? *d + v : v;
+    // the other sharers of a face / edge / vertex DoF add their part (ds_add_f64) ...
+    if (out_active) {
+      STFEM_UNROLL
+      for (int y = 0; y < N; ++y)
+        STFEM_UNROLL
+      for (int x = 0; x < N; ++x) {
+        if (x < P && y < P) continue;
+        const bool owned = (x < P || own_x_hi) && (y < P || own_y_hi);
+        if (!owned) atomicAdd(&a[y * TX + x], PA[y * N + x]);
       }
     }
+    // ... as do the plane carried over from the previous layer and the x-slab values
+    if (layer > 0)
+      for (int j = 0; j < prm.nbo; ++j)
+        for (int e = tid; e < PLANE; e += 256) atomicAdd(&acc[j * N * PLANE + e], carry[j * PLANE + e]);
+    STFEM_UNROLL
+    for (int m = 0; m < XE; ++m)
+      if (xe_idx[m] >= 0) atomicAdd(&acc[xe_idx[m]], xe[m]);
+    __syncthreads();
+
+    // stream the finished planes to their destination: k = 0..P-1, and k = P on the last layer
+    const int kend = last_layer ? N : P;
+    for (int j = 0; j < prm.nbo; ++j) {
+      double *dj = prm.dst[j] + tile_goff;
+      for (int kk = 0; kk < kend; ++kk) {
+        const int zl = P * layer + kk; // chunk-local plane
+        const double *ap = acc + (j * N + kk) * PLANE + lane_aoff;
+        if (kk == P && !t.last_z) { // top plane of an inner chunk: to the z-halo slab
+          double *zp = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + hw * tp.tX + X;
+          for (int Y = hw, o = 0; Y < ymax; Y += 8, ++o)
+            if (x_lane) zp[o * 8 * tp.tX] = ap[o * 8 * TX];
+        } else {
+          double *dp = dj + plane_stride * zl + lane_goff;
+          double *xs = xslab_out + (j * tp.zp + zl) * tp.tY;
+          for (int Y = hw, o = 0; Y < ymax; Y += 8, ++o) {
+            if (!x_lane) continue;
+            const double v = ap[o * 8 * TX];
+            if (divert_lane) xs[Y] = v;
+            else if (tp.add) dp[o * 8 * prm.nx] += v;
+            else dp[o * 8 * prm.nx] = v;
+          }
+        }
+      }
+    }
+    if (!t.last_y) // row Y = yext of every finished plane: to the y-halo slab
+      for (int r = hw; r < prm.nbo * kend; r += 8) {
+        const int j = r / kend, kk = r - j * kend;
+        if (x_lane)
+          tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + P * layer + kk) * tp.tX + X] =
+            acc[((j * N + kk) * TY + yext) * TX + X];
+      }
+    if (!last_layer) // top plane: carried to the next layer
+      for (int j = 0; j < prm.nbo; ++j)
+        for (int e = tid; e < PLANE; e += 256) carry[j * PLANE + e] = acc[(j * N + P) * PLANE + e];
     __syncthreads(); // slab free again for the next layer's transposes
   }
 }
 
-// Adds the halo partial sums of the lower neighbours to the DoFs a tile owns on its x = 0,
-// y = 0 and z = 0 faces.  One workgroup per tile.
+// Adds the halo partial sums of the lower y / z neighbours to the rows a tile owns on its y = 0
+// and z = 0 faces.  One workgroup per tile; rows are contiguous in x.
 template <int P>
 __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, const TilePlan tp, int nbm)
 {
-  const TileCoords t = tile_coords(prm, tp, blockIdx.x);
+  const int id = blockIdx.x;
+  const TileCoords t = tile_coords(prm, tp, id % tp.ntx, (id / tp.ntx) % tp.nty, id / (tp.ntx * tp.nty));
   const int has_x = t.tx > 0, has_y = t.ty > 0, has_z = t.tc > 0;
-  if (!(has_x | has_y | has_z)) return;
+  if (!(has_y | has_z)) return;
   // owned local extents
   const int Xn = P * t.ncx + (t.last_x ? 1 : 0), Yn = P * t.ncy + (t.last_y ? 1 : 0),
             Zn = P * t.nlay + (t.last_z ? 1 : 0);
-  const int xs = has_x ? 1 : 0, ys = has_y ? 1 : 0;
-  const int nfx = has_x ? Yn * Zn : 0;                      // X = 0, all Y, Z
-  const int nfy = has_y ? (Xn - xs) * Zn : 0;               // Y = 0, X >= xs
-  const int nfz = has_z ? (Xn - xs) * (Yn - ys) : 0;        // Z = 0, X >= xs, Y >= ys
+  const int ys = has_y ? 1 : 0;
+  const int nfy = has_y ? Xn * Zn : 0;        // Y = 0, all X, Z
+  const int nfz = has_z ? Xn * (Yn - ys) : 0; // Z = 0, Y >= ys
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
-  for (int idx = threadIdx.x; idx < nfx + nfy + nfz; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < nfy + nfz; idx += blockDim.x) {
     int X, Y, Z;
-    if (idx < nfx) {
-      X = 0; Y = idx % Yn; Z = idx / Yn;
-    } else if (idx < nfx + nfy) {
-      const int q = idx - nfx;
-      Y = 0; X = xs + q % (Xn - xs); Z = q / (Xn - xs);
+    if (idx < nfy) {
+      Y = 0; X = idx % Xn; Z = idx / Xn;
     } else {
-      const int q = idx - nfx - nfy;
-      Z = 0; X = xs + q % (Xn - xs); Y = ys + q / (Xn - xs);
+      const int q = idx - nfy;
+      Z = 0; X = q % Xn; Y = ys + q / Xn;
     }
     const int64_t g = int64_t(P) * t.cx0 + X + int64_t(prm.nx) * (int64_t(P) * t.cy0 + Y) +
                       plane_stride * (int64_t(P) * t.cz0 + Z);
     for (int j = 0; j < prm.nbo; ++j) {
       double s = 0.0;
       for (int dz = 0; dz <= (Z == 0 ? has_z : 0); ++dz)
-        for (int dy = 0; dy <= (Y == 0 ? has_y : 0); ++dy)
+        for (int dy = 0; dy <= (Y == 0 ? has_y : 0); ++dy) {
+          if (!(dy | dz)) continue;
           for (int dx = 0; dx <= (X == 0 ? has_x : 0); ++dx) {
-            if (!(dx | dy | dz)) continue;
-            const int ntx_ = t.tx - dx, nty_ = t.ty - dy, ntc_ = t.tc - dz;
-            const int nid = ntx_ + tp.ntx * (nty_ + tp.nty * ntc_);
-            // the DoF in the neighbour's local coordinates (neighbours below are never ragged)
-            const int Xp = dx ? P * tp.cw : X, Yp = dy ? P * tp.rows : Y, Zp = dz ? P * tp.lz : Z;
+            const int nid = (t.tx - dx) + tp.ntx * ((t.ty - dy) + tp.nty * (t.tc - dz));
+            // the DoF in the neighbour's local coordinates (lower neighbours are never ragged
+            // in the direction they are lower in)
+            const int Xp = dx ? P * tp.cw : X, Zp = dz ? P * tp.lz : Z;
             const int64_t base = int64_t(nid) * nbm + j;
-            if (dx) s += tp.xh[(base * tp.zp + Zp) * tp.tY + Yp];
-            else if (dy) s += tp.yh[(base * tp.zp + Zp) * tp.tX + Xp];
-            else s += tp.zh[(base * tp.tY + Yp) * tp.tX + Xp];
+            if (dy) s += tp.yh[(base * tp.zp + Zp) * tp.tX + Xp];
+            else s += tp.zh[(base * tp.tY + Y) * tp.tX + Xp];
           }
+        }
       prm.dst[j][g] += s;
     }
   }
 }
 
-template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePlan &tp, hipStream_t st)
+template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePlan &tp0, hipStream_t st)
 {
-  const int nblocks = tp.ntx * tp.nty * tp.ntc;
-  hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM>), dim3(nblocks), dim3(256), 0, st, prm, tp);
-  if (hipGetLastError() != hipSuccess) return -3;
-  if (tp.ntx > 1 || tp.nty > 1 || tp.ntc > 1) {
-    hipLaunchKernelGGL((st_tile_fixup<P>), dim3(nblocks), dim3(256), 0, st, prm, tp, NBM);
+  TilePlan tp = tp0;
+  for (int colour = 1; colour >= 0; --colour) { // odd tiles first: they feed the even ones
+    tp.xcolor = colour;
+    const int ntxh = (tp.ntx - colour + 1) / 2;
+    const int nblocks = ntxh * tp.nty * tp.ntc;
+    if (nblocks == 0) continue;
+    hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    if (hipGetLastError() != hipSuccess) return -3;
+  }
+  if (tp.nty > 1 || tp.ntc > 1) {
+    hipLaunchKernelGGL((st_tile_fixup<P>), dim3(tp.ntx * tp.nty * tp.ntc), dim3(256), 0, st, prm, tp, NBM);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   return 0;
@@ -288,6 +380,8 @@ int tile_geometry(int p, int nbm, TilePlan &plan)
   const int cb = 64 / n;
   if (nbm > cb) return -2;
   plan.cw = cb / nbm;
+  // the store phase maps one slab row to 32 lanes
+  if (p * plan.cw + 1 > 32) plan.cw = 31 / p;
   plan.rows = 4;
   plan.tX = p * plan.cw + 1;
   plan.tY = p * plan.rows + 1;
