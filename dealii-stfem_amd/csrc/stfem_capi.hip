@@ -384,6 +384,8 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
         tp.xl = tp.zh + nzh;
         tp.xr = tp.xl + nxs;
         tp.add = (add || !first) ? 1 : 0;
+        tp.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
+        tp.stagger = getenv("STFEM_STAGGER") ? atoi(getenv("STFEM_STAGGER")) : 0;
         rc = launch_cart_tile(c->p, prm, tp, st);
         c->last_kernel = cart_tile_name(c->p, nbm);
       }

@@ -68,6 +68,9 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
         Ua[y * N + z] = fma(aK[i], v, Ua[y * N + z]);
         R[y * N + z] = fma(aM[i], v, R[y * N + z]);
       }
+      // one block's reads in flight at a time (2 x 25 values would cost 100 more VGPRs)
+      pin(Ua);
+      pin(R);
     }
   }
   plane_sweep<N, +1, true>(prm.eo_Si, Ua);

@@ -25,6 +25,8 @@
 // dst.add(...) traffic of SystemMatrix::vmult (operators.h:536-559).
 #include "stfem_core.h"
 
+#include <cstdlib>
+
 namespace stfem {
 
 namespace {
@@ -40,8 +42,9 @@ template <int P, int NBM> struct TileGeom {
   static constexpr int ACC = NBM * N * PLANE;              // accumulation slab (aliases trans)
   static constexpr int TRANS = G::WAVES * G::LDS_PER_WAVE; // transpose slabs
   static constexpr int MAIN = ACC > TRANS ? ACC : TRANS;
-  static constexpr int CARRY = NBM * PLANE;
-  static constexpr int LDS_DOUBLES = MAIN + CARRY;
+  static constexpr int CARRY = NBM * PLANE;                // top plane carried between layers
+  static constexpr int CARRY_REGS = (CARRY + 255) / 256;   // ... in registers, CARRY_REGS per thread
+  static constexpr int LDS_DOUBLES = MAIN;
 };
 
 struct TileCoords {
@@ -88,16 +91,15 @@ __device__ __forceinline__ void load_plane(const double *__restrict__ s, int nx,
   for (int x = 0; x < N; ++x) PA[y * N + x] = s[int64_t(y) * nx + x];
 }
 
-template <int P, int NBM>
-__global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
+template <int P, int NBM, int MINW, bool ADD, bool COEF>
+__global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 {
   using TG = TileGeom<P, NBM>;
   using G = Geometry<P, NBM>;
   constexpr int N = TG::N;
   constexpr int TX = TG::TX, TY = TG::TY, PLANE = TG::PLANE;
   __shared__ double smem[TG::LDS_DOUBLES];
-  double *acc = smem;              // [blk][k][Y][X], aliases the transpose slabs
-  double *carry = smem + TG::MAIN; // [blk][Y][X]: top plane of the previous layer
+  double *acc = smem; // [blk][k][Y][X], aliases the transpose slabs
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -141,9 +143,6 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
   const bool xy_boundary = ((prm.dmask & 1) && t.tx == 0) || ((prm.dmask & 2) && t.last_x) ||
                            ((prm.dmask & 4) && t.ty == 0) || ((prm.dmask & 8) && t.last_y);
 
-  for (int e = tid; e < TG::CARRY; e += 256) carry[e] = 0.0;
-  __syncthreads();
-
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
   const int64_t xy_base = int64_t(P) * cx + int64_t(prm.nx) * (int64_t(P) * cy);
   // lanes that feed nothing still load from a valid address; their planes are never used
@@ -164,10 +163,26 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
   const int nrows = prm.nbo * N * TY;
   const int64_t tile_goff = int64_t(P) * t.cx0 + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
                             plane_stride * (int64_t(P) * t.cz0);
-  const int lane_goff = X + prm.nx * hw, lane_aoff = hw * TX + X;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_goff = X + prm.nx * (lane >> 5), lane_zoff = X + tp.tX * (lane >> 5);
+  const int lane_aoff = hw * TX + X;
 
-  double PN[N * N];
-  load_plane<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PN);
+  // top plane of the previous layer: element tid + 256*m of [blk][Y][X] lives in this thread
+  double carry[TG::CARRY_REGS];
+  STFEM_UNROLL
+  for (int m = 0; m < TG::CARRY_REGS; ++m) carry[m] = 0.0;
+
+  double PA[N * N];
+  load_plane<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
+  const int ex = tp.experiment;
+  // stagger: the two workgroups of a CU start together with identical work and would otherwise
+  // run their compute and their memory phases in lockstep; delaying the one in the odd wave slot
+  // lets one stream while the other computes
+  if (tp.stagger > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
+    if (hwid & 1)
+      for (int i = 0; i < tp.stagger; ++i) __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles each
+  }
 
   for (int layer = 0; layer < t.nlay; ++layer) {
     const int cz = t.cz0 + layer;
@@ -175,9 +190,6 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
     const bool z_boundary = ((prm.dmask & 16) && cz == 0) || ((prm.dmask & 32) && cz == prm.ncz - 1);
     const bool masked = xy_boundary || z_boundary;
     PlaneMask pm = plane_mask<P>(prm, cx, cy, cz, k);
-    double PA[N * N];
-    STFEM_UNROLL
-    for (int e = 0; e < N * N; ++e) PA[e] = PN[e];
     if (masked) {
       STFEM_UNROLL
       for (int y = 0; y < N; ++y)
@@ -185,11 +197,8 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
       for (int x = 0; x < N; ++x)
         if (constrained<P>(pm, y, x)) PA[y * N + x] = 0.0;
     }
-    // prefetch the next layer's plane while this one is being processed
-    if (!last_layer) load_plane<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PN);
-
     double aK[NBM], aM[NBM];
-    {
+    if (COEF) { // per-cell coefficients (operators.h:1060-1087) folded into the temporal weights
       const int64_t c = cell_xy + cells_per_layer * cz;
       const double fK = prm.coef_lap ? prm.coef_lap[c] : 1.0;
       const double fM = prm.coef_mass ? prm.coef_mass[c] : 1.0;
@@ -197,6 +206,12 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
       for (int i = 0; i < NBM; ++i) {
         aK[i] = aK0[i] * fK;
         aM[i] = aM0[i] * fM;
+      }
+    } else {
+      STFEM_UNROLL
+      for (int i = 0; i < NBM; ++i) {
+        aK[i] = aK0[i];
+        aM[i] = aM0[i];
       }
     }
 
@@ -225,7 +240,11 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
       }
     }
 
-    cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
+    if (!(ex & 2)) cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
+    // the slab values have long arrived; consuming them here on every path keeps the compiler
+    // from draining the src prefetch (issued below) when their registers are recycled later
+    STFEM_UNROLL
+    for (int m = 0; m < XE; ++m) asm volatile("" : "+v"(xe[m]));
 
     if (masked) {
       STFEM_UNROLL
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
     __syncthreads(); // all waves are done with the transpose slabs: the region becomes `acc`
 
     // owner lanes initialise their DoFs
-    if (out_active) {
+    if (out_active && !(ex & 4)) {
       STFEM_UNROLL
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
     }
     __syncthreads();
     // the other sharers of a face / edge / vertex DoF add their part (ds_add_f64) ...
-    if (out_active) {
+    if (out_active && !(ex & 4)) {
       STFEM_UNROLL
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
@@ -260,48 +279,78 @@ __global__ __launch_bounds__(256, 2) void st_sweep_cart_tile(const SweepParams p
       }
     }
     // ... as do the plane carried over from the previous layer and the x-slab values
-    if (layer > 0)
-      for (int j = 0; j < prm.nbo; ++j)
-        for (int e = tid; e < PLANE; e += 256) atomicAdd(&acc[j * N * PLANE + e], carry[j * PLANE + e]);
+    if (layer > 0) {
+      STFEM_UNROLL
+      for (int m = 0; m < TG::CARRY_REGS; ++m) {
+        const int e = tid + 256 * m, j = e / PLANE;
+        if (e < prm.nbo * PLANE) atomicAdd(&acc[j * (N - 1) * PLANE + e], carry[m]);
+      }
+    }
     STFEM_UNROLL
     for (int m = 0; m < XE; ++m)
       if (xe_idx[m] >= 0) atomicAdd(&acc[xe_idx[m]], xe[m]);
+    // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
+    // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
+    if (!last_layer && !(ex & 1)) load_plane<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA);
     __syncthreads();
 
-    // stream the finished planes to their destination: k = 0..P-1, and k = P on the last layer
+    // stream the finished planes to their destination: k = 0..P-1, and k = P on the last layer.
+    // Fully unrolled with predicates: with loops here the compiler drains the prefetch loads
+    // above (s_waitcnt vmcnt(0)) before the first store.
     const int kend = last_layer ? N : P;
-    for (int j = 0; j < prm.nbo; ++j) {
-      double *dj = prm.dst[j] + tile_goff;
-      for (int kk = 0; kk < kend; ++kk) {
-        const int zl = P * layer + kk; // chunk-local plane
-        const double *ap = acc + (j * N + kk) * PLANE + lane_aoff;
-        if (kk == P && !t.last_z) { // top plane of an inner chunk: to the z-halo slab
-          double *zp = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + hw * tp.tX + X;
-          for (int Y = hw, o = 0; Y < ymax; Y += 8, ++o)
-            if (x_lane) zp[o * 8 * tp.tX] = ap[o * 8 * TX];
-        } else {
-          double *dp = dj + plane_stride * zl + lane_goff;
+    if (!(ex & 8)) {
+      constexpr int NO = (TY + 7) / 8; // rows per half-wave and plane
+      STFEM_UNROLL
+      for (int j = 0; j < NBM; ++j) {
+        if (j >= prm.nbo) continue;
+        // all LDS reads of this block first, then all stores: a VMEM store keeps its address and
+        // data VGPRs locked until it has completed (vmcnt), so they must not be recycled
+        // from one store to the next
+        double sv[N][NO];
+        STFEM_UNROLL
+        for (int kk = 0; kk < N; ++kk)
+          STFEM_UNROLL
+        for (int o = 0; o < NO; ++o)
+          sv[kk][o] = (kk < kend && hw + 8 * o < ymax && x_lane) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : 0.0;
+        double *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u); // wave-uniform
+        double *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+        STFEM_UNROLL
+        for (int kk = 0; kk < N; ++kk) {
+          if (kk >= kend) continue;
+          const int zl = P * layer + kk; // chunk-local plane
+          const bool to_zh = kk == P && !t.last_z; // top plane of an inner chunk: z-halo slab
           double *xs = xslab_out + (j * tp.zp + zl) * tp.tY;
-          for (int Y = hw, o = 0; Y < ymax; Y += 8, ++o) {
-            if (!x_lane) continue;
-            const double v = ap[o * 8 * TX];
-            if (divert_lane) xs[Y] = v;
-            else if (tp.add) dp[o * 8 * prm.nx] += v;
-            else dp[o * 8 * prm.nx] = v;
+          STFEM_UNROLL
+          for (int o = 0; o < NO; ++o) {
+            const int Y = hw + 8 * o;
+            if (Y < ymax && x_lane) {
+              const double v = sv[kk][o];
+              if (to_zh) (zj + o * 8 * tp.tX)[lane_zoff] = v;
+              else if (divert_lane) xs[Y] = v;
+              else if (ADD) (dj + plane_stride * zl + int64_t(o * 8) * prm.nx)[lane_goff] += v;
+              else (dj + plane_stride * zl + int64_t(o * 8) * prm.nx)[lane_goff] = v;
+            }
           }
         }
       }
-    }
-    if (!t.last_y) // row Y = yext of every finished plane: to the y-halo slab
-      for (int r = hw; r < prm.nbo * kend; r += 8) {
-        const int j = r / kend, kk = r - j * kend;
-        if (x_lane)
-          tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + P * layer + kk) * tp.tX + X] =
-            acc[((j * N + kk) * TY + yext) * TX + X];
+      if (!t.last_y) { // row Y = yext of every finished plane: to the y-halo slab
+        STFEM_UNROLL
+        for (int o = 0; o < (NBM * N + 7) / 8; ++o) {
+          const int r = hw + 8 * o;
+          const int j = r / kend, kk = r - j * kend;
+          if (r < prm.nbo * kend && x_lane)
+            tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + P * layer + kk) * tp.tX + X] =
+              acc[((j * N + kk) * TY + yext) * TX + X];
+        }
       }
-    if (!last_layer) // top plane: carried to the next layer
-      for (int j = 0; j < prm.nbo; ++j)
-        for (int e = tid; e < PLANE; e += 256) carry[j * PLANE + e] = acc[(j * N + P) * PLANE + e];
+    }
+    if (!last_layer) { // top plane: carried to the next layer
+      STFEM_UNROLL
+      for (int m = 0; m < TG::CARRY_REGS; ++m) {
+        const int e = tid + 256 * m, j = e / PLANE;
+        if (e < prm.nbo * PLANE) carry[m] = acc[(j * (N - 1) + P) * PLANE + e];
+      }
+    }
     __syncthreads(); // slab free again for the next layer's transposes
   }
 }
@@ -360,7 +409,17 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
     const int ntxh = (tp.ntx - colour + 1) / 2;
     const int nblocks = ntxh * tp.nty * tp.ntc;
     if (nblocks == 0) continue;
-    hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    static const int minw = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 3;
+    (void)minw;
+    const bool coef = prm.coef_lap || prm.coef_mass;
+    if (tp.add && coef)
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, true, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    else if (tp.add)
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    else if (coef)
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    else
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   if (tp.nty > 1 || tp.ntc > 1) {
