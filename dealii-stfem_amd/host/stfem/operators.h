@@ -1,0 +1,179 @@
+// Host-side mirror of the reference's operator interface (include/operators.h) on the C-ABI:
+// same class names, method names, argument meaning and error behaviour (exceptions instead of
+// deal.II Assert/AssertThrow), so a caller written against the reference's duck-typed operator
+// concept (vmult / Tvmult / vmult_slice(_add) / initialize_dof_vector / m / n) compiles against
+// these classes.  Everything heavy happens behind libstfem_hip.so.
+#pragma once
+#include "fe_time.h"
+#include "types.h"
+
+#include <cmath>
+
+namespace stfem {
+
+// Structured hexahedral mesh of one rank (GridGenerator::subdivided_hyper_rectangle +
+// refine_global [+ distort_random], tests/tp_01.cc:82-90) and zero Dirichlet boundary ids.
+struct Mesh {
+  int ncell[3] = {1, 1, 1};
+  double lower[3] = {0, 0, 0}, upper[3] = {1, 1, 1};
+  std::vector<double> vertices; // empty = Cartesian box
+  int dirichlet_mask = 63;
+  int device = 0;
+
+  void distort_random(double factor, uint64_t seed = 5489)
+  {
+    vertices.resize(size_t(ncell[0] + 1) * (ncell[1] + 1) * (ncell[2] + 1) * 3);
+    check(stfem_mesh_vertices(ncell, lower, upper, factor, seed, 0, ncell[2], vertices.data()),
+          "stfem_mesh_vertices");
+  }
+};
+
+// include/operators.h:967-1191.  n_components must be 1, dim must be 3 in this round.
+template <int dim, int n_components, typename Number> class MatrixFreeOperator {
+  static_assert(dim == 3 && n_components == 1, "scalar 3D path");
+
+public:
+  using VectorType = VectorT<Number>;
+  using BlockVectorType = BlockVectorT<Number>;
+
+  // reference: (mapping, dof_handler, constraints, quadrature, mass_scaling, laplace_scaling);
+  // here the mesh + degree stand for mapping/dof_handler/constraints/QGauss(degree+1)
+  MatrixFreeOperator(const Mesh &mesh, unsigned fe_degree, double mass_matrix_scaling, double laplace_matrix_scaling)
+    : mass_matrix_scaling(mass_matrix_scaling), laplace_matrix_scaling(laplace_matrix_scaling)
+  {
+    ctx_ = make_context(mesh, fe_degree);
+  }
+  // K and M of one SystemMatrix share the MatrixFree data: build the second from the first
+  MatrixFreeOperator(const MatrixFreeOperator &other, double mass_matrix_scaling, double laplace_matrix_scaling)
+    : mass_matrix_scaling(mass_matrix_scaling), laplace_matrix_scaling(laplace_matrix_scaling), ctx_(other.ctx_)
+  {}
+
+  template <typename Number2> void initialize_dof_vector(VectorT<Number2> &vec) const { vec.reinit(ctx_); }
+
+  void vmult(VectorType &dst, const VectorType &src, void *stream = nullptr) const
+  {
+    check(stfem_space_vmult(ctx_->h, mass_matrix_scaling, laplace_matrix_scaling, dst.handle(), src.handle(), stream),
+          "MatrixFreeOperator::vmult");
+  }
+
+  // operators.h:1060-1087; one value per cell, or per (cell, quadrature point)
+  void evaluate_coefficient(const std::vector<double> &values)
+  {
+    const size_t ncells = size_t(stfem_n_cells(ctx_->h));
+    const int layout = values.size() == ncells ? 1 : 2;
+    const int which = laplace_matrix_scaling != 0.0 ? 1 : 0;
+    check(stfem_set_coefficient(ctx_->h, which, layout, values.data()), "evaluate_coefficient");
+  }
+
+  unsigned long long m() const { return (unsigned long long)stfem_n_dofs(ctx_->h); }
+  Number el(unsigned, unsigned) const { throw std::logic_error("MatrixFreeOperator::el is not implemented"); }
+
+  VectorType get_matrix_diagonal(void *stream = nullptr) const
+  {
+    VectorType d;
+    d.reinit(ctx_);
+    check(stfem_diagonal(ctx_->h, mass_matrix_scaling, laplace_matrix_scaling, d.handle(), stream),
+          "get_matrix_diagonal");
+    return d;
+  }
+
+  const std::shared_ptr<Context> &context() const { return ctx_; }
+  const double mass_matrix_scaling, laplace_matrix_scaling;
+
+private:
+  static std::shared_ptr<Context> make_context(const Mesh &mesh, unsigned degree)
+  {
+    stfem_mesh_desc md{};
+    for (int d = 0; d < 3; ++d) {
+      md.ncell[d] = mesh.ncell[d];
+      md.lower[d] = mesh.lower[d];
+      md.upper[d] = mesh.upper[d];
+    }
+    md.vertices = mesh.vertices.empty() ? nullptr : mesh.vertices.data();
+    md.dirichlet_mask = mesh.dirichlet_mask;
+    md.device = mesh.device;
+    stfem_space_desc sd{int32_t(degree), int32_t(degree + 1), 1};
+    stfem_ctx *c = nullptr;
+    check(stfem_ctx_create(&md, &sd, &c), "stfem_ctx_create");
+    return std::make_shared<Context>(c);
+  }
+  std::shared_ptr<Context> ctx_;
+};
+template <int dim, typename Number> using MatrixFreeOperatorScalar = MatrixFreeOperator<dim, 1, Number>;
+
+// include/operators.h:328-663 (SystemMatrixBase + SystemMatrix): A = Alpha (x) K + Beta (x) M
+template <int dim, typename Number, typename SystemMatrixTypeK, typename SystemMatrixTypeM = SystemMatrixTypeK>
+class SystemMatrix {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  using VectorType = VectorT<Number>;
+
+  // The reference keeps references to K, M, Alpha, Beta (operators.h:465-469); callers keep them alive.
+  SystemMatrix(const SystemMatrixTypeK &K, const SystemMatrixTypeM &M, const FullMatrix<Number> &Alpha_,
+               const FullMatrix<Number> &Beta_)
+    : K(K), M(M), Alpha(Alpha_), Beta(Beta_), alpha_is_zero(Alpha_.all_zero()), beta_is_zero(Beta_.all_zero())
+  {
+    if (Alpha.m() != Beta.m() || Alpha.n() != Beta.n()) throw std::invalid_argument("Alpha/Beta shape mismatch");
+    if (K.context() != M.context()) throw std::invalid_argument("K and M must share one MatrixFree context");
+    if (K.laplace_matrix_scaling != 1.0 || K.mass_matrix_scaling != 0.0 || M.mass_matrix_scaling != 1.0 ||
+        M.laplace_matrix_scaling != 0.0)
+      throw std::invalid_argument("fused path expects K = (0,1) and M = (1,0) as in tests/tp_01.cc:114-117");
+  }
+  virtual ~SystemMatrix() = default;
+
+  virtual void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    apply(dst, src, 0, 0, stream);
+  }
+  virtual void Tvmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    apply(dst, src, 1, 0, stream);
+  }
+  // n x 1 case for rhs assembly (operators.h:377-382, 586-611)
+  virtual void vmult_slice_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    apply(dst, src, 0, 1, stream);
+  }
+  void vmult_slice(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    apply(dst, src, 0, 0, stream);
+  }
+  virtual void form(BlockVectorType &dst, const BlockVectorType &src) const { vmult(dst, src); }
+
+  unsigned long long m() const { return Alpha.m() * M.m(); }
+  unsigned long long n() const { return m(); }
+  Number el(unsigned, unsigned) const { throw std::logic_error("SystemMatrix::el is not implemented"); }
+
+  template <typename Number2> void initialize_dof_vector(VectorT<Number2> &vec, unsigned = 1) const
+  {
+    vec.reinit(K.context());
+  }
+  template <typename Number2> void initialize_dof_vector(BlockVectorT<Number2> &vec) const
+  {
+    vec.reinit(K.context(), Alpha.m());
+  }
+
+private:
+  void apply(BlockVectorType &dst, const BlockVectorType &src, int transpose, int add, void *stream) const
+  {
+    check(stfem_st_vmult(K.context()->h, int(Alpha.m()), int(Alpha.n()), Alpha.data(), Beta.data(), transpose, add,
+                         dst.handle(), src.handle(), stream),
+          "SystemMatrix::vmult");
+  }
+  const SystemMatrixTypeK &K;
+  const SystemMatrixTypeM &M;
+  const FullMatrix<Number> &Alpha;
+  const FullMatrix<Number> &Beta;
+  bool alpha_is_zero, beta_is_zero;
+};
+
+// operators.h:211-283 tensorproduct_add: c_i += A(i,j) b_j
+template <typename Number>
+void tensorproduct_add(const std::shared_ptr<Context> &ctx, BlockVectorT<Number> &c, const FullMatrix<Number> &A,
+                       const BlockVectorT<Number> &b, void *stream = nullptr)
+{
+  check(stfem_tensorproduct_add(ctx->h, int(A.m()), int(A.n()), A.data(), c.handle(), b.handle(), stream),
+        "tensorproduct_add");
+}
+
+} // namespace stfem

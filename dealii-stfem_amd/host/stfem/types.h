@@ -1,0 +1,127 @@
+// Host-side mirror of the reference's vector types (include/types.h:19-36) on top of the C-ABI.
+// VectorT<Number>  ~ dealii::LinearAlgebra::distributed::Vector<Number>      (one spatial vector)
+// BlockVectorT     ~ dealii::LinearAlgebra::distributed::BlockVector<Number> (one per temporal DoF)
+// Only Number = double is built on the device in this round.
+#pragma once
+#include "../../../include/stfem.h"
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace stfem {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string &what)
+    : std::runtime_error(what + ": " + stfem_strerror(s) + " [" + stfem_last_hip_error() + "]"), status(s) {}
+};
+inline void check(int status, const char *what)
+{
+  if (status != STFEM_OK) throw Error(status, what);
+}
+
+// minimal stand-in for dealii::FullMatrix<Number> (row-major)
+template <typename Number> class FullMatrix {
+public:
+  FullMatrix() = default;
+  FullMatrix(unsigned m, unsigned n) : m_(m), n_(n), v_(size_t(m) * n, Number(0)) {}
+  unsigned m() const { return m_; }
+  unsigned n() const { return n_; }
+  Number &operator()(unsigned i, unsigned j) { return v_[size_t(i) * n_ + j]; }
+  const Number &operator()(unsigned i, unsigned j) const { return v_[size_t(i) * n_ + j]; }
+  bool all_zero() const
+  {
+    for (const Number &x : v_)
+      if (x != Number(0)) return false;
+    return true;
+  }
+  const Number *data() const { return v_.data(); }
+  Number *data() { return v_.data(); }
+
+private:
+  unsigned m_ = 0, n_ = 0;
+  std::vector<Number> v_;
+};
+
+// owning handle of an stfem_ctx, shared by the K and M operators of one mesh
+struct Context {
+  stfem_ctx *h = nullptr;
+  explicit Context(stfem_ctx *c) : h(c) {}
+  ~Context() { stfem_ctx_destroy(h); }
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+};
+
+template <typename Number> class BlockVectorT;
+
+template <typename Number> class VectorT {
+  static_assert(sizeof(Number) == sizeof(double), "device path is built for double");
+
+public:
+  VectorT() = default;
+  void reinit(const std::shared_ptr<Context> &ctx)
+  {
+    ctx_ = ctx;
+    stfem_vec *v = nullptr;
+    check(stfem_vector_create(ctx->h, 1, &v), "stfem_vector_create");
+    v_.reset(v, stfem_vector_destroy);
+  }
+  size_t size() const { return ctx_ ? size_t(stfem_n_dofs(ctx_->h)) : 0; }
+  void copy_from_host(const std::vector<Number> &h)
+  {
+    const double *p[1] = {h.data()};
+    check(stfem_vector_upload(v_.get(), p), "stfem_vector_upload");
+  }
+  std::vector<Number> copy_to_host() const
+  {
+    std::vector<Number> h(size());
+    double *p[1] = {h.data()};
+    check(stfem_vector_download(v_.get(), p), "stfem_vector_download");
+    return h;
+  }
+  stfem_vec *handle() const { return v_.get(); }
+  const std::shared_ptr<Context> &context() const { return ctx_; }
+
+private:
+  std::shared_ptr<Context> ctx_;
+  std::shared_ptr<stfem_vec> v_;
+};
+
+template <typename Number> class BlockVectorT {
+public:
+  BlockVectorT() = default;
+  void reinit(const std::shared_ptr<Context> &ctx, unsigned n_blocks)
+  {
+    ctx_ = ctx;
+    nb_ = n_blocks;
+    stfem_vec *v = nullptr;
+    check(stfem_vector_create(ctx->h, int(n_blocks), &v), "stfem_vector_create");
+    v_.reset(v, stfem_vector_destroy);
+  }
+  unsigned n_blocks() const { return nb_; }
+  size_t block_size() const { return ctx_ ? size_t(stfem_n_dofs(ctx_->h)) : 0; }
+  void copy_from_host(const std::vector<std::vector<Number>> &h)
+  {
+    std::vector<const double *> p;
+    for (const auto &b : h) p.push_back(b.data());
+    check(stfem_vector_upload(v_.get(), p.data()), "stfem_vector_upload");
+  }
+  std::vector<std::vector<Number>> copy_to_host() const
+  {
+    std::vector<std::vector<Number>> h(nb_, std::vector<Number>(block_size()));
+    std::vector<double *> p;
+    for (auto &b : h) p.push_back(b.data());
+    check(stfem_vector_download(v_.get(), p.data()), "stfem_vector_download");
+    return h;
+  }
+  stfem_vec *handle() const { return v_.get(); }
+
+private:
+  std::shared_ptr<Context> ctx_;
+  std::shared_ptr<stfem_vec> v_;
+  unsigned nb_ = 0;
+};
+
+} // namespace stfem
