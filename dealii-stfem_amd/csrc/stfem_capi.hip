@@ -337,6 +337,7 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
   fill_common(c, prm);
   prm.coef_lap = use_lap_coef ? c->d_coef[1] : nullptr;
   prm.coef_mass = use_mass_coef ? c->d_coef[0] : nullptr;
+  prm.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
   for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS) {
     bool first = true; // first launch into this row panel overwrites dst unless add
     for (int i0 = 0; i0 < nbi; i0 += MAX_BLOCKS) {

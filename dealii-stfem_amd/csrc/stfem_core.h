@@ -40,6 +40,8 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   constexpr int N = G::N;
   constexpr int CBS = G::CBS;
   double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+  const bool no_lds = prm.experiment & 256;
+  if (no_lds) { in_active = false; out_active = false; }
 
   // ---- phase A: interpolate x, y (registers), hand over to layout B
   plane_sweep<N, +1, true>(prm.eo_Si, PA);
@@ -52,31 +54,39 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   }
   wave_lds_fence();
 
-  // ---- phase B: temporal combination, interpolate z, mass + y/z Laplacian
+  // ---- phase B: temporal combination, interpolate z, mass + y/z Laplacian.
+  // Row by row (fixed y, line along z): combine the input blocks, interpolate both combinations
+  // and apply the z Laplacian while only one line is in flight, so that the peak register need
+  // stays at the two result planes plus one line.
   double Ua[N * N], R[N * N];
   STFEM_UNROLL
-  for (int e = 0; e < N * N; ++e) Ua[e] = R[e] = 0.0;
-  STFEM_UNROLL
-  for (int i = 0; i < NBM; ++i) {
-    if (i < prm.nbi) {
-      const double *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
-      STFEM_UNROLL
-      for (int y = 0; y < N; ++y)
+  for (int y = 0; y < N; ++y) {
+    double ua[N], ub[N];
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) ua[z] = ub[z] = 0.0;
+    STFEM_UNROLL
+    for (int i = 0; i < NBM; ++i) {
+      if (i < prm.nbi) {
+        const double *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
         STFEM_UNROLL
-      for (int z = 0; z < N; ++z) {
-        const double v = in_lds[z * N * N + y * N + k];
-        Ua[y * N + z] = fma(aK[i], v, Ua[y * N + z]);
-        R[y * N + z] = fma(aM[i], v, R[y * N + z]);
+        for (int z = 0; z < N; ++z) {
+          const double v = no_lds ? 1.0 + z : in_lds[z * N * N + y * N + k];
+          ua[z] = fma(aK[i], v, ua[z]);
+          ub[z] = fma(aM[i], v, ub[z]);
+        }
       }
-      // one block's reads in flight at a time (2 x 25 values would cost 100 more VGPRs)
-      pin(Ua);
-      pin(R);
+    }
+    double ta[N], tb[N], tl[N];
+    eo_apply<N, +1>(prm.eo_Si, ua, ta);
+    eo_apply<N, +1>(prm.eo_Si, ub, tb);
+    // Cartesian cell, coefficient constant in the cell: D^T c D collapses to c * L (one sweep)
+    eo_apply<N, +1>(prm.eo_L, ta, tl);
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) {
+      Ua[y * N + z] = ta[z];
+      R[y * N + z] = fma(prm.ihz2, tl[z], tb[z]);
     }
   }
-  plane_sweep<N, +1, true>(prm.eo_Si, Ua);
-  plane_sweep<N, +1, true>(prm.eo_Si, R);
-  // Cartesian cell, coefficient constant in the cell: D^T c D collapses to c * L (one sweep)
-  plane_sweep_acc<N, true>(prm.eo_L, prm.ihz2, Ua, R);
   plane_sweep_acc<N, false>(prm.eo_L, prm.ihy2, Ua, R);
   pin(R);
   wave_lds_fence();
@@ -92,7 +102,7 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   STFEM_UNROLL
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
-  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  for (int x = 0; x < N; ++x) PA[y * N + x] = no_lds ? Ua[y * N + x] : cb_lds[k * N * N + y * N + x];
   plane_sweep_scaled<N, true>(prm.eo_L, prm.ihx2, PA);
   wave_lds_fence();
   if (out_active) {
@@ -107,7 +117,7 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   STFEM_UNROLL
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
-  for (int z = 0; z < N; ++z) R[y * N + z] += cb_lds[z * N * N + y * N + k];
+  for (int z = 0; z < N; ++z) R[y * N + z] += no_lds ? PA[y * N + z] : cb_lds[z * N * N + y * N + k];
   plane_sweep_T<N, true>(prm.eo_Si, R);
   wave_lds_fence();
   if (out_active) {
@@ -122,7 +132,7 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   STFEM_UNROLL
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
-  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  for (int x = 0; x < N; ++x) PA[y * N + x] = no_lds ? R[y * N + x] : cb_lds[k * N * N + y * N + x];
   plane_sweep_T<N, false>(prm.eo_Si, PA);
   plane_sweep_T<N, true>(prm.eo_Si, PA);
   wave_lds_fence();

@@ -21,6 +21,7 @@ struct SweepParams {
   double ihx2, ihy2, ihz2;
   const double *coef_lap;  // per cell or nullptr
   const double *coef_mass; // per cell or nullptr
+  int experiment;          // ablation bits for cell_core (256: no LDS traffic in the core); results wrong if set
   double eo_Si[EO_N], eo_L[EO_N]; // even-odd packed: interpolation (weights folded), 1D Laplacian
 };
 

@@ -91,6 +91,51 @@ __device__ __forceinline__ void load_plane(const double *__restrict__ s, int nx,
   for (int x = 0; x < N; ++x) PA[y * N + x] = s[int64_t(y) * nx + x];
 }
 
+// The same gather issued through inline asm: the compiler does not track these loads, so it
+// will not drain them (and, vmcnt being in-order, every store issued after them) with a
+// vmcnt(0) at the next use.  The caller waits with wait_vmcnt(n), n <= number of VMEM
+// instructions this wave has issued since, before touching PA.
+template <int P>
+__device__ __forceinline__ void load_plane_async(const double *s, int nx, double (&PA)[(P + 1) * (P + 1)])
+{
+  constexpr int N = P + 1;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y) {
+    const double *row = s + int64_t(y) * nx;
+    STFEM_UNROLL
+    for (int x = 0; x + 1 < N; x += 2) {
+      d2 v;
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(v) : "v"(row), "n"(x * 8) : "memory");
+      PA[y * N + x] = v.x;
+      PA[y * N + x + 1] = v.y;
+    }
+    if (N & 1) {
+      double v;
+      asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(v) : "v"(row), "n"((N - 1) * 8) : "memory");
+      PA[y * N + N - 1] = v;
+    }
+  }
+}
+
+template <int CNT> __device__ __forceinline__ void wait_vmcnt_imm()
+{
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+}
+// waits until at most n (wave-uniform, clamped to [0, 32]) VMEM operations are outstanding
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n >= 32) wait_vmcnt_imm<32>();
+  else if (n >= 24) wait_vmcnt_imm<24>();
+  else if (n >= 20) wait_vmcnt_imm<20>();
+  else if (n >= 16) wait_vmcnt_imm<16>();
+  else if (n >= 12) wait_vmcnt_imm<12>();
+  else if (n >= 8) wait_vmcnt_imm<8>();
+  else if (n >= 4) wait_vmcnt_imm<4>();
+  else wait_vmcnt_imm<0>();
+}
+
 template <int P, int NBM, int MINW, bool ADD, bool COEF>
 __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 {
@@ -149,23 +194,16 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   const double *src_lane = prm.src[in_active ? blk : 0] + xy_base + plane_stride * k;
   double *a = acc + ((blk * N + k) * TY + P * cyl) * TX + P * cxl;
 
-  // store phase: one row of the slab per half-wave (32 lanes, X = lane within the half)
-  const int hw = 2 * wave + (lane >> 5), X = lane & 31;
   const int xext = P * t.ncx, yext = P * t.ncy;
-  const bool x_lane = X <= xext;
   const int ymax = t.last_y ? yext + 1 : yext; // rows [0, ymax) go to dst, row yext to yh otherwise
   // x faces: odd tiles divert their shared columns to the x-slabs, even tiles collect them
   const bool odd = tp.xcolor == 1;
-  const bool divert_lane = odd && (X == 0 || (X == xext && !t.last_x));
-  double *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
   const bool collect_left = !odd && t.tx > 0, collect_right = !odd && !t.last_x;
   constexpr int XE = (2 * NBM * N * TY + 255) / 256; // slab values per thread and layer
   const int nrows = prm.nbo * N * TY;
   const int64_t tile_goff = int64_t(P) * t.cx0 + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
                             plane_stride * (int64_t(P) * t.cz0);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned lane_goff = X + prm.nx * (lane >> 5), lane_zoff = X + tp.tX * (lane >> 5);
-  const int lane_aoff = hw * TX + X;
 
   // top plane of the previous layer: element tid + 256*m of [blk][Y][X] lives in this thread
   double carry[TG::CARRY_REGS];
@@ -173,7 +211,8 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   for (int m = 0; m < TG::CARRY_REGS; ++m) carry[m] = 0.0;
 
   double PA[N * N];
-  load_plane<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
+  load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
+  wait_vmcnt_imm<0>();
   const int ex = tp.experiment;
   // stagger: the two workgroups of a CU start together with identical work and would otherwise
   // run their compute and their memory phases in lockstep; delaying the one in the odd wave slot
@@ -184,6 +223,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       for (int i = 0; i < tp.stagger; ++i) __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles each
   }
 
+  double dummy = 0.0;
   for (int layer = 0; layer < t.nlay; ++layer) {
     const int cz = t.cz0 + layer;
     const bool last_layer = layer == t.nlay - 1;
@@ -218,24 +258,30 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     // even tiles: fetch the odd neighbours' partial sums of the shared columns for this layer
     // (issued before the compute, consumed after it)
     double xe[XE];
-    int xe_idx[XE];
     STFEM_UNROLL
-    for (int m = 0; m < XE; ++m) {
-      xe[m] = 0.0;
-      xe_idx[m] = -1;
-    }
+    for (int m = 0; m < XE; ++m) xe[m] = 0.0;
+    // slab entry m of this thread: (side, row) -> LDS slab index or -1; evaluated twice (here for
+    // the load, after the core for the add) rather than kept in registers across the core
+    auto xe_slot = [&](int m, int &side, int &j, int &kk, int &Y) -> int {
+      const int e = tid + 256 * m;
+      side = e >= nrows ? 1 : 0;
+      const int row = e - side * nrows;
+      Y = row % TY;
+      const int jk = row / TY;
+      kk = jk % N;
+      j = jk / N;
+      const bool to_dst = Y < ymax && (kk < P || (last_layer && t.last_z));
+      const bool ok = e < 2 * nrows && to_dst && (side == 0 ? collect_left : collect_right);
+      return ok ? row * TX + (side == 0 ? 0 : xext) : -1;
+    };
     if (collect_left || collect_right) {
       STFEM_UNROLL
       for (int m = 0; m < XE; ++m) {
-        const int e = tid + 256 * m;
-        const int side = e >= nrows ? 1 : 0, row = e - side * nrows;
-        const int Y = row % TY, jk = row / TY, kk = jk % N, j = jk / N;
-        const bool to_dst = Y < ymax && (kk < P || (last_layer && t.last_z));
-        if (e < 2 * nrows && to_dst && (side == 0 ? collect_left : collect_right)) {
+        int side, j, kk, Y;
+        if (xe_slot(m, side, j, kk, Y) >= 0) {
           const int nid = tile_id + (side == 0 ? -1 : 1);
           const double *slab = (side == 0 ? tp.xr : tp.xl) + int64_t(nid) * NBM * tp.zp * tp.tY;
           xe[m] = slab[(j * tp.zp + P * layer + kk) * tp.tY + Y];
-          xe_idx[m] = row * TX + (side == 0 ? 0 : xext);
         }
       }
     }
@@ -286,12 +332,17 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         if (e < prm.nbo * PLANE) atomicAdd(&acc[j * (N - 1) * PLANE + e], carry[m]);
       }
     }
-    STFEM_UNROLL
-    for (int m = 0; m < XE; ++m)
-      if (xe_idx[m] >= 0) atomicAdd(&acc[xe_idx[m]], xe[m]);
+    if (collect_left || collect_right) {
+      STFEM_UNROLL
+      for (int m = 0; m < XE; ++m) {
+        int side, j, kk, Y;
+        const int idx = xe_slot(m, side, j, kk, Y);
+        if (idx >= 0) atomicAdd(&acc[idx], xe[m]);
+      }
+    }
     // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
     // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
-    if (!last_layer && !(ex & 1)) load_plane<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA);
+    if (!last_layer && !(ex & 1)) load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA);
     __syncthreads();
 
     // stream the finished planes to their destination: k = 0..P-1, and k = P on the last layer.
@@ -300,6 +351,17 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     const int kend = last_layer ? N : P;
     if (!(ex & 8)) {
       constexpr int NO = (TY + 7) / 8; // rows per half-wave and plane
+      // store-phase lane roles: one slab row per half-wave (32 lanes, X = lane within the half).
+      // Derived from a laundered lane id so that they are recomputed here instead of being kept
+      // in ~15 VGPRs across the register-critical core.
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      const int hw = 2 * wave_u + (lane_s >> 5), X = lane_s & 31;
+      const bool x_lane = X <= xext;
+      const bool divert_lane = odd && (X == 0 || (X == xext && !t.last_x));
+      double *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
+      const unsigned lane_goff = X + prm.nx * (lane_s >> 5), lane_zoff = X + tp.tX * (lane_s >> 5);
+      const int lane_aoff = hw * TX + X;
       STFEM_UNROLL
       for (int j = 0; j < NBM; ++j) {
         if (j >= prm.nbo) continue;
@@ -311,7 +373,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         for (int kk = 0; kk < N; ++kk)
           STFEM_UNROLL
         for (int o = 0; o < NO; ++o)
-          sv[kk][o] = (kk < kend && hw + 8 * o < ymax && x_lane) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : 0.0;
+          sv[kk][o] = (kk < kend && hw + 8 * o < ymax && x_lane && !(ex & 32)) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : 0.0;
         double *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u); // wave-uniform
         double *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
         STFEM_UNROLL
@@ -323,6 +385,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
           STFEM_UNROLL
           for (int o = 0; o < NO; ++o) {
             const int Y = hw + 8 * o;
+            if (ex & 64) { dummy += sv[kk][o]; continue; }
             if (Y < ymax && x_lane) {
               const double v = sv[kk][o];
               if (to_zh) (zj + o * 8 * tp.tX)[lane_zoff] = v;
@@ -333,7 +396,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
           }
         }
       }
-      if (!t.last_y) { // row Y = yext of every finished plane: to the y-halo slab
+      if (!t.last_y && !(ex & 128)) { // row Y = yext of every finished plane: to the y-halo slab
         STFEM_UNROLL
         for (int o = 0; o < (NBM * N + 7) / 8; ++o) {
           const int r = hw + 8 * o;
@@ -352,7 +415,17 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       }
     }
     __syncthreads(); // slab free again for the next layer's transposes
+    // the prefetched planes must have landed before PA is touched; the stores issued after
+    // them may stay in flight.  Lower bound of the stores this wave has issued since: one per
+    // (block, plane, row group) whose first half-wave row exists.
+    {
+      int n_o = 0;
+      STFEM_UNROLL
+      for (int o = 0; o < (TY + 7) / 8; ++o) n_o += (2 * wave_u + 8 * o < ymax) ? 1 : 0;
+      wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
+    }
   }
+  if (dummy == 1.2345e300) tp.zh[0] = dummy; // experiment sink, never true
 }
 
 // Adds the halo partial sums of the lower y / z neighbours to the rows a tile owns on its y = 0
@@ -401,7 +474,7 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
   }
 }
 
-template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePlan &tp0, hipStream_t st)
+template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, const TilePlan &tp0, hipStream_t st)
 {
   TilePlan tp = tp0;
   for (int colour = 1; colour >= 0; --colour) { // odd tiles first: they feed the even ones
@@ -409,17 +482,15 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
     const int ntxh = (tp.ntx - colour + 1) / 2;
     const int nblocks = ntxh * tp.nty * tp.ntc;
     if (nblocks == 0) continue;
-    static const int minw = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 3;
-    (void)minw;
     const bool coef = prm.coef_lap || prm.coef_mass;
     if (tp.add && coef)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, true, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else if (tp.add)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else if (coef)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   if (tp.nty > 1 || tp.ntc > 1) {
@@ -427,6 +498,12 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
     if (hipGetLastError() != hipSuccess) return -3;
   }
   return 0;
+}
+
+template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePlan &tp, hipStream_t st)
+{
+  static const int minw = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 2;
+  return minw == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
 }
 
 } // namespace
