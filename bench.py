@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--cells", type=int, default=72, help="cells per direction per GPU")
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--time-degree", type=int, default=2)
+    ap.add_argument("--distort", type=float, default=0.0,
+                    help="interior-vertex jitter in units of h (0.15 = BASELINE configs[2] mesh); 0 = Cartesian")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=16)
     args = ap.parse_args()
@@ -95,9 +97,15 @@ def main():
     tau = 1.0 / 144
     Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, r, tau, 1)
     nb = Alpha.shape[0]
-    ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=(0, 0, float(slab.z0) / n),
-                                   upper=(1, 1, float(slab.z1) / n),
-                                   dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
+    if args.distort:
+        verts = stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, float(world)), args.distort, 5489,
+                                    z_range=(slab.z0, slab.z1))
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=verts,
+                                       dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
+    else:
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=(0, 0, float(slab.z0) / n),
+                                       upper=(1, 1, float(slab.z1) / n),
+                                       dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
     A = stfem.SystemMatrix(ctx, Alpha, Beta)
     ndofs = ctx.n_dofs
     nx = p * n + 1
@@ -187,9 +195,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D heat, Q{p} x cG({r}), {n}x{n}x{n * world} cells Cartesian unit-"
-                                   f"spacing slab mesh, {total_dofs} space-time DoFs"
-                                   + (" = BASELINE configs[1]" if (world, n, p, r) == (1, 72, 4, 2) else ""),
+            "config": {"workload": f"3D heat, Q{p} x cG({r}), {n}x{n}x{n * world} cells "
+                                   + (f"perturbed ({args.distort} h vertex jitter)" if args.distort else "Cartesian")
+                                   + f" slab mesh, {total_dofs} space-time DoFs"
+                                   + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else ""),
                        "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
                        "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

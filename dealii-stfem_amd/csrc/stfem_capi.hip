@@ -50,6 +50,10 @@ struct stfem_ctx {
   double *d_halo = nullptr;
   size_t halo_doubles = 0;
   int variant = 0; // 0 = tile (default), 1 = atomic
+  // general-geometry path: device copies of vertices and the 1D rule, metric terms per (cell, q)
+  double *d_vertices = nullptr, *d_rule = nullptr, *d_metric = nullptr;
+  bool metric_valid = false;
+  int metric_flags = -1; // which coefficients are baked into d_metric (bit0 laplace, bit1 mass)
 };
 
 struct stfem_vec {
@@ -165,6 +169,9 @@ void stfem_ctx_destroy(stfem_ctx *c)
     if (p) (void)hipFree(p);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_halo) (void)hipFree(c->d_halo);
+  if (c->d_vertices) (void)hipFree(c->d_vertices);
+  if (c->d_rule) (void)hipFree(c->d_rule);
+  if (c->d_metric) (void)hipFree(c->d_metric);
   delete c;
 }
 
@@ -182,6 +189,7 @@ int stfem_set_coefficient(stfem_ctx *c, int which, int layout, const double *hos
     c->d_coef[which] = nullptr;
   }
   c->coef_layout[which] = 0;
+  c->metric_valid = false;
   if (layout == 0) return STFEM_OK;
   if (!host) return STFEM_ERR_INVALID_ARGUMENT;
   const int nq = c->p + 1;
@@ -289,6 +297,9 @@ static void fill_common(const stfem_ctx *c, SweepParams &prm)
   const int ne = eo_size(c->p + 1);
   std::memcpy(prm.eo_Si, c->tab.eo_Si, ne * sizeof(double));
   std::memcpy(prm.eo_L, c->tab.eo_L, ne * sizeof(double));
+  std::memcpy(prm.eo_S, c->tab.eo_S, ne * sizeof(double));
+  std::memcpy(prm.eo_Dq, c->tab.eo_Dq, ne * sizeof(double));
+  std::memcpy(prm.eo_DqT, c->tab.eo_DqT, ne * sizeof(double));
 }
 
 // Chooses the z-chunking of the tile variant: enough workgroups to fill 2 per CU several times
@@ -316,6 +327,48 @@ static void plan_chunks(const stfem_ctx *c, TilePlan &tp)
   tp.zp = c->p * lz + 1;
 }
 
+// (Re)builds the per-quadrature-point metric of the general path.  The coefficients in force
+// (operators.h:1152-1162: a coefficient replaces the scaling) are baked in; the flags record
+// which of them were used so that a K-only / M-only apply with a different set rebuilds.
+static int ensure_metric(stfem_ctx *c, bool use_lap, bool use_mass, hipStream_t st)
+{
+  static_assert(sizeof(double) == 8, "");
+  const int n = c->p + 1;
+  const size_t nm = size_t(c->ncells) * 7 * n * n * n;
+  const int flags = (use_lap ? 1 : 0) | (use_mass ? 2 : 0);
+  if (c->metric_valid && c->metric_flags == flags) return STFEM_OK;
+  if (!c->d_vertices) {
+    std::vector<double> v = c->vertices;
+    if (v.empty()) { // Cartesian box given by extents
+      v.resize(size_t(c->nc[0] + 1) * (c->nc[1] + 1) * (c->nc[2] + 1) * 3);
+      size_t o = 0;
+      for (int k = 0; k <= c->nc[2]; ++k)
+        for (int j = 0; j <= c->nc[1]; ++j)
+          for (int i = 0; i <= c->nc[0]; ++i, ++o) {
+            v[3 * o] = c->lower[0] + c->h[0] * i;
+            v[3 * o + 1] = c->lower[1] + c->h[1] * j;
+            v[3 * o + 2] = c->lower[2] + c->h[2] * k;
+          }
+    }
+    if (hipMalloc(&c->d_vertices, v.size() * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+    HIP_TRY(hipMemcpy(c->d_vertices, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> rule(c->tab.xq);
+    rule.insert(rule.end(), c->tab.wq.begin(), c->tab.wq.end());
+    if (hipMalloc(&c->d_rule, rule.size() * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+    HIP_TRY(hipMemcpy(c->d_rule, rule.data(), rule.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (!c->d_metric && hipMalloc(&c->d_metric, nm * sizeof(double)) != hipSuccess)
+    return STFEM_ERR_OUT_OF_MEMORY;
+  const int rc = launch_build_metric(c->p, c->nc, c->d_vertices, c->d_rule, c->d_rule + n,
+                                     use_lap ? c->d_coef[1] : nullptr, use_lap ? c->coef_layout[1] : 0,
+                                     use_mass ? c->d_coef[0] : nullptr, use_mass ? c->coef_layout[0] : 0,
+                                     c->d_metric, st);
+  if (rc != 0) return hip_fail(hipGetLastError(), "build_metric");
+  c->metric_valid = true;
+  c->metric_flags = flags;
+  return STFEM_OK;
+}
+
 // a(j,i), b(j,i): effective nbo x nbi matrices (row-major)
 static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,
                        const std::vector<double> &b, stfem_vec *dst, const stfem_vec *src, int add,
@@ -326,17 +379,24 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
   for (int j = 0; j < nbo; ++j)
     for (int i = 0; i < nbi; ++i)
       if (dst->blk[j] == src->blk[i]) return STFEM_ERR_ALIAS;
-  if (!c->cartesian) return STFEM_ERR_UNSUPPORTED;
-  for (int w = 0; w < 2; ++w)
-    if (c->coef_layout[w] == 2) return STFEM_ERR_UNSUPPORTED;
-  const bool atomic = c->variant == 1;
+  // general path: non-Cartesian cells or per-quadrature-point coefficients -> metric terms
+  const bool general = !c->cartesian || c->coef_layout[0] == 2 || c->coef_layout[1] == 2;
+  if (general) {
+    const int rc = ensure_metric(c, use_lap_coef, use_mass_coef, st);
+    if (rc != STFEM_OK) return rc;
+  }
+  const bool atomic = c->variant == 1 && !general;
   if (!add && atomic)
     for (int j = 0; j < nbo; ++j)
       HIP_TRY(hipMemsetAsync(dst->blk[j], 0, size_t(c->ndofs) * sizeof(double), st));
   SweepParams prm;
   fill_common(c, prm);
-  prm.coef_lap = use_lap_coef ? c->d_coef[1] : nullptr;
-  prm.coef_mass = use_mass_coef ? c->d_coef[0] : nullptr;
+  prm.coef_lap = (use_lap_coef && !general) ? c->d_coef[1] : nullptr;
+  prm.coef_mass = (use_mass_coef && !general) ? c->d_coef[0] : nullptr;
+  if (general) {
+    prm.metric = c->d_metric;
+    prm.vol = 1.0; // detJ and the weights live in the metric
+  }
   prm.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
   for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS) {
     bool first = true; // first launch into this row panel overwrites dst unless add

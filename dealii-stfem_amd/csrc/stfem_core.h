@@ -138,6 +138,175 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   wave_lds_fence();
 }
 
+// General-geometry variant of cell_core (MappingQ1 cells of any shape, per-quadrature-point
+// coefficients): the reference's evaluate -> quadrature loop -> integrate
+// (include/operators.h:1135-1173) with unweighted S and collocation derivative D; the metric
+// terms  G = c_L w detJ J^-1 J^-T (6 entries)  and  Mq = c_M w detJ  come precomputed per
+// quadrature point from HBM (as deal.II's MatrixFree stores them), `met` = this cell's
+// [7][qz][qy][qx] block.  Six wave-private transposes instead of four: the x derivative lives in
+// layout A, the flux contraction needs all three gradient components at one point (layout B).
+template <int P, int NBM>
+__device__ __forceinline__ void
+cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, int blk, int k,
+                  bool in_active, bool out_active, const double (&aK)[NBM], const double (&aM)[NBM],
+                  const double *__restrict__ met, double (&PA)[(P + 1) * (P + 1)])
+{
+  using G = Geometry<P, NBM>;
+  constexpr int N = G::N;
+  constexpr int CBS = G::CBS;
+  constexpr int N3 = N * N * N;
+  double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+
+  // ---- A: interpolate x, y
+  plane_sweep<N, +1, true>(prm.eo_S, PA);
+  plane_sweep<N, +1, false>(prm.eo_S, PA);
+  if (in_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int x = 0; x < N; ++x) cb_lds[k * N * N + y * N + x] = PA[y * N + x];
+  }
+  wave_lds_fence();
+
+  // ---- B1: temporal combination + interpolate z: Ua (Laplace part), R (mass part) at the
+  // quadrature points of this lane's x-plane
+  double Ua[N * N], R[N * N];
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y) {
+    double ua[N], ub[N];
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) ua[z] = ub[z] = 0.0;
+    STFEM_UNROLL
+    for (int i = 0; i < NBM; ++i) {
+      if (i < prm.nbi) {
+        const double *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
+        STFEM_UNROLL
+        for (int z = 0; z < N; ++z) {
+          const double v = in_lds[z * N * N + y * N + k];
+          ua[z] = fma(aK[i], v, ua[z]);
+          ub[z] = fma(aM[i], v, ub[z]);
+        }
+      }
+    }
+    double ta[N], tb[N];
+    eo_apply<N, +1>(prm.eo_S, ua, ta);
+    eo_apply<N, +1>(prm.eo_S, ub, tb);
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) {
+      Ua[y * N + z] = ta[z];
+      R[y * N + z] = tb[z];
+    }
+  }
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int z = 0; z < N; ++z) cb_lds[z * N * N + y * N + k] = Ua[y * N + z];
+  }
+  wave_lds_fence();
+
+  // ---- A2: reference x derivative in layout A, back to layout B
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  plane_sweep<N, -1, true>(prm.eo_Dq, PA);
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int x = 0; x < N; ++x) cb_lds[k * N * N + y * N + x] = PA[y * N + x];
+  }
+  wave_lds_fence();
+
+  // ---- B3: y derivative (whole plane), then point by point: z derivative, metric, fluxes
+  double Gy[N * N];
+  STFEM_UNROLL
+  for (int z = 0; z < N; ++z) {
+    double x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = Ua[i * N + z];
+    eo_apply<N, -1>(prm.eo_Dq, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) Gy[i * N + z] = y[i];
+  }
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y) {
+    double ur[N], gzr[N], fz[N], t[N];
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) ur[z] = Ua[y * N + z];
+    eo_apply<N, -1>(prm.eo_Dq, ur, gzr);
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) {
+      const int q = z * N * N + y * N + k;
+      const double gx = cb_lds[q], gy = Gy[y * N + z], gz = gzr[z];
+      const double Gxx = met[q], Gxy = met[N3 + q], Gxz = met[2 * N3 + q], Gyy = met[3 * N3 + q],
+                   Gyz = met[4 * N3 + q], Gzz = met[5 * N3 + q], Mq = met[6 * N3 + q];
+      const double fx = fma(Gxx, gx, fma(Gxy, gy, Gxz * gz));
+      const double fy = fma(Gxy, gx, fma(Gyy, gy, Gyz * gz));
+      fz[z] = fma(Gxz, gx, fma(Gyz, gy, Gzz * gz));
+      R[y * N + z] *= Mq;
+      Gy[y * N + z] = fy;
+      if (out_active) cb_lds[q] = fx; // this lane's own column: read above, rewritten here
+    }
+    eo_apply<N, -1>(prm.eo_DqT, fz, t);
+    STFEM_UNROLL
+    for (int z = 0; z < N; ++z) R[y * N + z] += t[z];
+  }
+  STFEM_UNROLL
+  for (int z = 0; z < N; ++z) { // R += Dy^T Fy
+    double x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = Gy[i * N + z];
+    eo_apply<N, -1>(prm.eo_DqT, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) R[i * N + z] += y[i];
+  }
+  pin(R);
+  wave_lds_fence();
+
+  // ---- A4: Dx^T of the x flux in layout A
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  plane_sweep<N, -1, true>(prm.eo_DqT, PA);
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int x = 0; x < N; ++x) cb_lds[k * N * N + y * N + x] = PA[y * N + x];
+  }
+  wave_lds_fence();
+
+  // ---- B5: collect, integrate z
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int z = 0; z < N; ++z) R[y * N + z] += cb_lds[z * N * N + y * N + k];
+  plane_sweep_T<N, true>(prm.eo_S, R);
+  wave_lds_fence();
+  if (out_active) {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int z = 0; z < N; ++z) cb_lds[z * N * N + y * N + k] = R[y * N + z];
+  }
+  wave_lds_fence();
+
+  // ---- A6: integrate y, x
+  STFEM_UNROLL
+  for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+  for (int x = 0; x < N; ++x) PA[y * N + x] = cb_lds[k * N * N + y * N + x];
+  plane_sweep_T<N, false>(prm.eo_S, PA);
+  plane_sweep_T<N, true>(prm.eo_S, PA);
+  wave_lds_fence();
+}
+
 // Dirichlet flags of the plane (cell, k): which local rows/columns are constrained.
 struct PlaneMask {
   bool x0, x1, y0, y1, all;

@@ -136,7 +136,7 @@ __device__ __forceinline__ void wait_vmcnt(int n)
   else wait_vmcnt_imm<0>();
 }
 
-template <int P, int NBM, int MINW, bool ADD, bool COEF>
+template <int P, int NBM, int MINW, bool ADD, bool COEF, bool GEN>
 __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 {
   using TG = TileGeom<P, NBM>;
@@ -286,7 +286,11 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       }
     }
 
-    if (!(ex & 2)) cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
+    if (GEN)
+      cell_core_general<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM,
+                                prm.metric + (cell_xy + cells_per_layer * cz) * (7 * N * N * N), PA);
+    else if (!(ex & 2))
+      cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
     // the slab values have long arrived; consuming them here on every path keeps the compiler
     // from draining the src prefetch (issued below) when their registers are recycled later
     STFEM_UNROLL
@@ -483,14 +487,19 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
     const int nblocks = ntxh * tp.nty * tp.ntc;
     if (nblocks == 0) continue;
     const bool coef = prm.coef_lap || prm.coef_mass;
-    if (tp.add && coef)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    if (prm.metric) { // general geometry / per-q coefficients (baked into the metric)
+      if (tp.add)
+        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, true, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      else
+        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, false, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+    } else if (tp.add && coef)
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else if (tp.add)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else if (coef)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   if (tp.nty > 1 || tp.ntc > 1) {
@@ -507,6 +516,79 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
 }
 
 } // namespace
+
+namespace {
+
+// One thread per (cell, quadrature point): MappingQ1 Jacobian from the 8 cell vertices, then
+// G = c_L w detJ J^-1 J^-T and Mq = c_M w detJ (what FEEvaluation::submit_gradient /
+// submit_value multiply with, reference include/operators.h:1149-1163).
+__global__ __launch_bounds__(256) void build_metric_kernel(int n, int ncx, int ncy, int64_t ncells,
+                                                            const double *__restrict__ vert,
+                                                            const double *__restrict__ xq,
+                                                            const double *__restrict__ wq,
+                                                            const double *__restrict__ cl, int cl_layout,
+                                                            const double *__restrict__ cm, int cm_layout,
+                                                            double *__restrict__ metric)
+{
+  const int n3 = n * n * n;
+  const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= ncells * n3) return;
+  const int64_t cell = gid / n3;
+  const int q = int(gid - cell * n3);
+  const int qx = q % n, qy = (q / n) % n, qz = q / (n * n);
+  const int cx = int(cell % ncx), cy = int((cell / ncx) % ncy), cz = int(cell / (int64_t(ncx) * ncy));
+  const int64_t nvx = ncx + 1, nvy = ncy + 1;
+  const double xi[3] = {xq[qx], xq[qy], xq[qz]};
+  double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int c = 0; c < 2; ++c)
+    for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < 2; ++a) {
+        const double *X = vert + 3 * ((cx + a) + nvx * ((cy + b) + nvy * int64_t(cz + c)));
+        const double fx = a ? xi[0] : 1.0 - xi[0], fy = b ? xi[1] : 1.0 - xi[1], fz = c ? xi[2] : 1.0 - xi[2];
+        const double dx = a ? 1.0 : -1.0, dy = b ? 1.0 : -1.0, dz = c ? 1.0 : -1.0;
+        for (int d = 0; d < 3; ++d) {
+          J[d][0] += X[d] * dx * fy * fz;
+          J[d][1] += X[d] * fx * dy * fz;
+          J[d][2] += X[d] * fx * fy * dz;
+        }
+      }
+  const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                     J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+  const double id = 1.0 / det;
+  double Ji[3][3]; // Ji[e][d] = d xi_e / d x_d
+  Ji[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+  Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * id;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+  Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+  const double JxW = det * wq[qx] * wq[qy] * wq[qz];
+  const double fl = cl_layout == 0 ? 1.0 : (cl_layout == 1 ? cl[cell] : cl[gid]);
+  const double fm = cm_layout == 0 ? 1.0 : (cm_layout == 1 ? cm[cell] : cm[gid]);
+  double *m = metric + cell * 7 * n3 + q;
+  int comp = 0;
+  for (int e = 0; e < 3; ++e)
+    for (int f = e; f < 3; ++f, ++comp)
+      m[comp * n3] = fl * JxW * (Ji[e][0] * Ji[f][0] + Ji[e][1] * Ji[f][1] + Ji[e][2] * Ji[f][2]);
+  m[6 * n3] = fm * JxW;
+}
+
+} // namespace
+
+int launch_build_metric(int p, const int nc[3], const double *d_vertices, const double *d_xq,
+                        const double *d_wq, const double *coef_lap, int lap_layout,
+                        const double *coef_mass, int mass_layout, double *d_metric, void *stream)
+{
+  const int n = p + 1;
+  const int64_t ncells = int64_t(nc[0]) * nc[1] * nc[2], total = ncells * n * n * n;
+  hipLaunchKernelGGL(build_metric_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n, nc[0], nc[1], ncells, d_vertices, d_xq, d_wq,
+                     coef_lap, lap_layout, coef_mass, mass_layout, d_metric);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int tile_geometry(int p, int nbm, TilePlan &plan)
 {

@@ -64,6 +64,81 @@ def test_golden_fixture(name, stfem, golden_dir):
         assert rel(dst.download(), ref[:1]) < TOL
 
 
+GENERAL_FIXTURES = ["q2_pert_2x3x2", "q3_pert_2x2x2", "q4_pert_3x2x2"]
+
+
+@pytest.mark.parametrize("name", GENERAL_FIXTURES)
+def test_golden_fixture_general_mesh(name, stfem, golden_dir):
+    """Perturbed (MappingQ1) cells with a per-quadrature-point laplace coefficient: the
+    general-geometry kernel against the independent numpy assembly."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ctx = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                   dirichlet_mask=int(g["mask"]))
+    assert not ctx.is_cartesian
+    ctx.evaluate_coefficient(g["coef_lap"], which=1)
+    assert rel(apply(stfem, ctx, g["Alpha"], g["Beta"], g["X"]), g["Y"]) < TOL
+    assert rel(apply(stfem, ctx, g["Alpha"], g["Beta"], g["X"], transpose=True), g["YT"]) < TOL
+    op = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                  dirichlet_mask=int(g["mask"]), laplace_matrix_scaling=1.0)
+    op.evaluate_coefficient(g["coef_lap"], which=1)
+    dst = stfem.BlockVector(op, 1)
+    op.vmult(dst, stfem.BlockVector(op, 1).upload(g["X"][:1]))
+    assert rel(dst.download(), g["KX"][:1]) < TOL
+    mop = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                   dirichlet_mask=int(g["mask"]), mass_matrix_scaling=1.0)
+    mop.vmult(dst2 := stfem.BlockVector(mop, 1), stfem.BlockVector(mop, 1).upload(g["X"][:1]))
+    assert rel(dst2.download(), g["MX"][:1]) < TOL
+
+
+GENERAL_CASES = [
+    # p, ncell, distort, mask, type, r, nsteps
+    (4, (7, 6, 5), 0.15, 63, "CGP", 2, 1),   # cfg 2 shape (perturbed hypercube), small
+    (2, (9, 5, 4), 0.15, 0, "CGP", 1, 4),
+    (3, (5, 4, 6), 0.1, 63, "DG", 2, 1),
+    (1, (4, 3, 3), 0.2, 0b101010, "DG", 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", GENERAL_CASES, ids=lambda c: f"Q{c[0]}-{c[4]}{c[5]}x{c[6]}-pert")
+def test_general_mesh_vs_oracle(case, stfem, oracle_mod):
+    p, nc, distort, mask, tt, r, ns = case
+    t = stfem.CGP if tt == "CGP" else stfem.DG
+    Alpha, Beta, Gamma, Zeta = stfem.get_fe_time_weights(t, r, 0.02, ns)
+    verts = stfem.mesh_vertices(nc, (0, 0, 0), (1, 1, 1), distort, 5489)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts, dirichlet_mask=mask)
+    assert not ctx.is_cartesian
+    orc = oracle_mod.Oracle(p, nc, verts, mask)
+    X = random_blocks(Alpha.shape[0], ctx.n_dofs)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    assert rel(apply(stfem, ctx, Alpha, Beta, X, transpose=True),
+               orc.st_vmult(Alpha, Beta, X, transpose=True)) < TOL
+    g = Gamma if np.any(Gamma) else Zeta
+    z = Zeta if np.any(Zeta) else Gamma
+    ref = orc.st_vmult(g, z, X[:1])
+    assert rel(apply(stfem, ctx, g, z, X[:1], add_to=ref), 2 * ref) < TOL
+    # per-quadrature-point coefficients on both operators
+    rng = np.random.default_rng(3)
+    cl = rng.uniform(0.5, 2.0, (ctx.n_cells, (p + 1) ** 3)); cm = rng.uniform(0.5, 2.0, (ctx.n_cells, (p + 1) ** 3))
+    ctx.evaluate_coefficient(cl, which=1); ctx.evaluate_coefficient(cm, which=0)
+    orc.set_coefficient(1, cl); orc.set_coefficient(0, cm)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+
+
+def test_per_q_coefficient_on_cartesian_mesh(stfem, oracle_mod):
+    p, nc = 2, (5, 4, 3)
+    verts = stfem.mesh_vertices(nc)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts)
+    assert ctx.is_cartesian
+    orc = oracle_mod.Oracle(p, nc, verts, 63)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.1, 1)
+    X = random_blocks(2, ctx.n_dofs)
+    cl = np.random.default_rng(8).uniform(0.5, 2.0, (ctx.n_cells, 27))
+    ctx.evaluate_coefficient(cl, which=1); orc.set_coefficient(1, cl)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    ctx.evaluate_coefficient(None, which=1); orc.set_coefficient(1, None)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+
+
 def random_blocks(n_blocks, n, seed=1234):
     return np.stack([np.random.default_rng(seed + b).uniform(-1, 1, n) for b in range(n_blocks)])
 
