@@ -232,8 +232,23 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) Gy[i * N + z] = y[i];
   }
+  // metric terms are streamed one row (fixed y, all z) ahead; the empty asm statements keep the
+  // compiler from hoisting every row's loads to the top (350 VGPRs of loads in flight)
+  double mrow[2][N][7];
+  STFEM_UNROLL
+  for (int z = 0; z < N; ++z)
+    STFEM_UNROLL
+  for (int c = 0; c < 7; ++c) mrow[0][z][c] = met[c * N3 + z * N * N + 0 * N + k];
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
+    if (y + 1 < N) {
+      const double *mp = met; // laundered: loads through it cannot be hoisted above this point
+      asm volatile("" : "+v"(mp));
+      STFEM_UNROLL
+      for (int z = 0; z < N; ++z)
+        STFEM_UNROLL
+      for (int c = 0; c < 7; ++c) mrow[(y + 1) & 1][z][c] = mp[c * N3 + z * N * N + (y + 1) * N + k];
+    }
     double ur[N], gzr[N], fz[N], t[N];
     STFEM_UNROLL
     for (int z = 0; z < N; ++z) ur[z] = Ua[y * N + z];
@@ -242,18 +257,18 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
     for (int z = 0; z < N; ++z) {
       const int q = z * N * N + y * N + k;
       const double gx = cb_lds[q], gy = Gy[y * N + z], gz = gzr[z];
-      const double Gxx = met[q], Gxy = met[N3 + q], Gxz = met[2 * N3 + q], Gyy = met[3 * N3 + q],
-                   Gyz = met[4 * N3 + q], Gzz = met[5 * N3 + q], Mq = met[6 * N3 + q];
-      const double fx = fma(Gxx, gx, fma(Gxy, gy, Gxz * gz));
-      const double fy = fma(Gxy, gx, fma(Gyy, gy, Gyz * gz));
-      fz[z] = fma(Gxz, gx, fma(Gyz, gy, Gzz * gz));
-      R[y * N + z] *= Mq;
+      const double *m = mrow[y & 1][z];
+      const double fx = fma(m[0], gx, fma(m[1], gy, m[2] * gz));
+      const double fy = fma(m[1], gx, fma(m[3], gy, m[4] * gz));
+      fz[z] = fma(m[2], gx, fma(m[4], gy, m[5] * gz));
+      R[y * N + z] *= m[6];
       Gy[y * N + z] = fy;
       if (out_active) cb_lds[q] = fx; // this lane's own column: read above, rewritten here
     }
     eo_apply<N, -1>(prm.eo_DqT, fz, t);
     STFEM_UNROLL
     for (int z = 0; z < N; ++z) R[y * N + z] += t[z];
+    pin(R); // row y is complete before the next row's loads are issued
   }
   STFEM_UNROLL
   for (int z = 0; z < N; ++z) { // R += Dy^T Fy

@@ -489,9 +489,9 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
     const bool coef = prm.coef_lap || prm.coef_mass;
     if (prm.metric) { // general geometry / per-q coefficients (baked into the metric)
       if (tp.add)
-        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, true, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 1, true, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
       else
-        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 2, false, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 1, false, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     } else if (tp.add && coef)
       hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
     else if (tp.add)
