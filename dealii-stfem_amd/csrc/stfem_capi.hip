@@ -490,7 +490,55 @@ int stfem_space_vmult(stfem_ctx *c, double ms, double ls, stfem_vec *dst, const 
   return apply_tiled(c, 1, 1, a, b, dst, src, 0, lc, mc, stream);
 }
 
-int stfem_diagonal(stfem_ctx *, double, double, stfem_vec *, void *) { return STFEM_ERR_UNSUPPORTED; }
+int stfem_diagonal(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *stream)
+{
+  if (!c || !diag || diag->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (diag->nb != 1) return STFEM_ERR_SHAPE_MISMATCH;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool lc = ls != 0.0 && c->coef_layout[1] != 0, mc = ms != 0.0 && c->coef_layout[0] != 0;
+  const bool general = !c->cartesian || c->coef_layout[0] == 2 || c->coef_layout[1] == 2;
+  if (general) {
+    const int rc = ensure_metric(c, lc, mc, st);
+    if (rc != STFEM_OK) return rc;
+  }
+  HIP_TRY(hipMemsetAsync(diag->blk[0], 0, size_t(c->ndofs) * sizeof(double), st));
+  DiagParams prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.diag = diag->blk[0];
+  prm.ncx = c->nc[0]; prm.ncy = c->nc[1]; prm.ncz = c->nc[2];
+  prm.nx = c->nd[0]; prm.ny = c->nd[1];
+  prm.p = c->p;
+  prm.dmask = c->dmask;
+  prm.ms = ms != 0.0 ? (mc ? 1.0 : ms) : 0.0; // operators.h:1152-1162
+  prm.ls = ls != 0.0 ? (lc ? 1.0 : ls) : 0.0;
+  prm.vol = c->h[0] * c->h[1] * c->h[2];
+  prm.ihx2 = 1.0 / (c->h[0] * c->h[0]);
+  prm.ihy2 = 1.0 / (c->h[1] * c->h[1]);
+  prm.ihz2 = 1.0 / (c->h[2] * c->h[2]);
+  const int n = c->p + 1;
+  if (general) {
+    prm.metric = c->d_metric;
+  } else {
+    prm.coef_lap = lc ? c->d_coef[1] : nullptr;
+    prm.coef_mass = mc ? c->d_coef[0] : nullptr;
+  }
+  for (int a = 0; a < n; ++a) {
+    double m = 0, l = 0;
+    for (int q = 0; q < n; ++q) {
+      m += c->tab.wq[q] * c->tab.S[q * n + a] * c->tab.S[q * n + a];
+      l += c->tab.wq[q] * c->tab.D[q * n + a] * c->tab.D[q * n + a];
+    }
+    prm.m1[a] = m;
+    prm.l1[a] = l;
+  }
+  for (int i = 0; i < n * n; ++i) {
+    prm.S[i] = c->tab.S[i];
+    prm.D[i] = c->tab.D[i];
+  }
+  if (launch_diagonal(prm, st) != 0) return hip_fail(hipGetLastError(), "diagonal launch");
+  return STFEM_OK;
+}
 
 // ------------------------------------------------------------------------------------ BLAS-1 / halo
 

@@ -54,6 +54,21 @@ struct TilePlan {
 int launch_cart_atomic(int p, const SweepParams &prm, void *stream);
 const char *cart_atomic_name(int p, int nbm);
 
+// Forward diagonal of ms*M_c + ls*K_c (reference operators.h:1092-1110), accumulated with fp64
+// atomics into a zeroed vector.  Cartesian cells use the 1D diagonals m1[a] = (S^T W S)_aa and
+// l1[a] = (S^T D^T W D S)_aa; general cells sum over the quadrature points with the metric.
+struct DiagParams {
+  double *diag;
+  int ncx, ncy, ncz, nx, ny, p, dmask;
+  double ms, ls;          // effective scalings (1 where a coefficient replaces them)
+  double vol, ihx2, ihy2, ihz2;
+  const double *coef_lap, *coef_mass; // per cell or nullptr (Cartesian path)
+  const double *metric;               // general path, coefficients baked in
+  double m1[8], l1[8];                // 1D diagonals (Cartesian)
+  double S[64], D[64];                // plain S[q][a], D[q][a] (general)
+};
+int launch_diagonal(const DiagParams &prm, void *stream);
+
 // Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm); returns 0 or -2.
 int tile_geometry(int p, int nbm, TilePlan &plan);
 int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);

@@ -94,6 +94,54 @@ template <int P, int NBM> int launch_atomic_t(const SweepParams &prm, hipStream_
 
 } // namespace
 
+namespace {
+
+__global__ __launch_bounds__(128) void diagonal_kernel(const DiagParams prm)
+{
+  const int n = prm.p + 1, n3 = n * n * n;
+  const int64_t cell = blockIdx.x;
+  const int cx = int(cell % prm.ncx), cy = int((cell / prm.ncx) % prm.ncy), cz = int(cell / (int64_t(prm.ncx) * prm.ncy));
+  for (int l = threadIdx.x; l < n3; l += blockDim.x) {
+    const int a = l % n, b = (l / n) % n, c = l / (n * n);
+    const int ix = prm.p * cx + a, iy = prm.p * cy + b, iz = prm.p * cz + c;
+    const bool con = ((prm.dmask & 1) && ix == 0) || ((prm.dmask & 2) && ix == prm.nx - 1) ||
+                     ((prm.dmask & 4) && iy == 0) || ((prm.dmask & 8) && iy == prm.ny - 1) ||
+                     ((prm.dmask & 16) && iz == 0) || ((prm.dmask & 32) && iz == prm.p * prm.ncz);
+    if (con) continue;
+    double v = 0.0;
+    if (prm.metric) {
+      const double *m = prm.metric + cell * 7 * n3;
+      for (int qz = 0; qz < n; ++qz)
+        for (int qy = 0; qy < n; ++qy)
+          for (int qx = 0; qx < n; ++qx) {
+            const int q = qx + n * (qy + n * qz);
+            const double sa = prm.S[qx * n + a], sb = prm.S[qy * n + b], sc = prm.S[qz * n + c];
+            const double val = sa * sb * sc;
+            const double g0 = prm.D[qx * n + a] * sb * sc, g1 = sa * prm.D[qy * n + b] * sc, g2 = sa * sb * prm.D[qz * n + c];
+            v += prm.ms * m[6 * n3 + q] * val * val +
+                 prm.ls * (m[q] * g0 * g0 + m[3 * n3 + q] * g1 * g1 + m[5 * n3 + q] * g2 * g2 +
+                           2.0 * (m[n3 + q] * g0 * g1 + m[2 * n3 + q] * g0 * g2 + m[4 * n3 + q] * g1 * g2));
+          }
+    } else {
+      const double fK = prm.vol * (prm.coef_lap ? prm.coef_lap[cell] : 1.0);
+      const double fM = prm.vol * (prm.coef_mass ? prm.coef_mass[cell] : 1.0);
+      v = prm.ms * fM * prm.m1[a] * prm.m1[b] * prm.m1[c] +
+          prm.ls * fK * (prm.ihx2 * prm.l1[a] * prm.m1[b] * prm.m1[c] + prm.ihy2 * prm.m1[a] * prm.l1[b] * prm.m1[c] +
+                         prm.ihz2 * prm.m1[a] * prm.m1[b] * prm.l1[c]);
+    }
+    unsafeAtomicAdd(prm.diag + ix + int64_t(prm.nx) * (iy + int64_t(prm.ny) * iz), v);
+  }
+}
+
+} // namespace
+
+int launch_diagonal(const DiagParams &prm, void *stream)
+{
+  const int64_t ncells = int64_t(prm.ncx) * prm.ncy * prm.ncz;
+  hipLaunchKernelGGL(diagonal_kernel, dim3((unsigned)ncells), dim3(128), 0, static_cast<hipStream_t>(stream), prm);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_cart_atomic(int p, const SweepParams &prm, void *stream)
 {
   hipStream_t st = static_cast<hipStream_t>(stream);

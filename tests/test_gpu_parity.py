@@ -266,3 +266,28 @@ def test_blas1_and_planes(stfem):
     assert abs(stfem.dot(ctx, b, b) - np.sum(X * X)) < 1e-10
     plane = 7 * 7
     assert abs(stfem.dot(ctx, b, b, n_own=n - plane) - np.sum(X[:, :n - plane] ** 2)) < 1e-10
+
+
+@pytest.mark.parametrize("name", CART_FIXTURES + GENERAL_FIXTURES)
+def test_diagonal(name, stfem, golden_dir):
+    """compute_diagonal (operators.h:1092-1110): forward diagonal of K and of M."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    for ms, ls, ref in ((0.0, 1.0, g["diagK"]), (1.0, 0.0, g["diagM"])):
+        op = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                      dirichlet_mask=int(g["mask"]), mass_matrix_scaling=ms,
+                                      laplace_matrix_scaling=ls)
+        if "coef_lap" in g.files and ls != 0.0:
+            op.evaluate_coefficient(g["coef_lap"], which=1)
+        d = op.compute_diagonal().download()[0]
+        assert rel(d, ref) < TOL
+
+
+def test_diagonal_with_cell_coefficient_vs_oracle(stfem, oracle_mod):
+    p, nc = 3, (4, 3, 2)
+    verts = stfem.mesh_vertices(nc, (-1, -1, -1), (1, 1, 1))
+    coef = stfem.coefficient_per_cell(nc, verts, 1, 9, 16, 0.5, (2, 1, 1), (-1, -1, -1), (1, 1, 1))
+    op = stfem.MatrixFreeOperator(p, nc, vertices=verts, laplace_matrix_scaling=1.0, mass_matrix_scaling=0.5)
+    op.evaluate_coefficient(coef, which=1)
+    orc = oracle_mod.Oracle(p, nc, verts, 63)
+    orc.set_coefficient(1, np.repeat(coef[:, None], (p + 1) ** 3, axis=1))
+    assert rel(op.compute_diagonal().download()[0], orc.diagonal(mass=0.5, laplace=1.0)) < TOL
