@@ -96,7 +96,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `make -C dealii-stfem_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("STFEM_LIB", LIB_PATH))  # STFEM_LIB: experiment builds only
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)
             f.restype = res

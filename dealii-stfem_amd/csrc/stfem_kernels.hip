@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void st_sweep_cart_atomic(const SweepParams pr
 
 template <int P, int NBM> int launch_atomic_t(const SweepParams &prm, hipStream_t st)
 {
+  (void)hipGetLastError(); // drop a stale sticky error of an unrelated earlier call
   using G = Geometry<P, NBM>;
   const int64_t cells_per_block = int64_t(G::CELLS_PER_WAVE) * G::WAVES;
   const int64_t blocks = (prm.ncells + cells_per_block - 1) / cells_per_block;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(128) void diagonal_kernel(const DiagParams prm)
 
 int launch_diagonal(const DiagParams &prm, void *stream)
 {
+  (void)hipGetLastError(); // drop a stale sticky error of an unrelated earlier call
   const int64_t ncells = int64_t(prm.ncx) * prm.ncy * prm.ncz;
   hipLaunchKernelGGL(diagonal_kernel, dim3((unsigned)ncells), dim3(128), 0, static_cast<hipStream_t>(stream), prm);
   return hipGetLastError() == hipSuccess ? 0 : -3;

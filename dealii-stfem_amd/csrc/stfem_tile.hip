@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
 template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, const TilePlan &tp0, hipStream_t st)
 {
   TilePlan tp = tp0;
+  (void)hipGetLastError(); // drop a stale sticky error of an unrelated earlier call
   for (int colour = 1; colour >= 0; --colour) { // odd tiles first: they feed the even ones
     tp.xcolor = colour;
     const int ntxh = (tp.ntx - colour + 1) / 2;
@@ -584,6 +585,7 @@ int launch_build_metric(int p, const int nc[3], const double *d_vertices, const 
 {
   const int n = p + 1;
   const int64_t ncells = int64_t(nc[0]) * nc[1] * nc[2], total = ncells * n * n * n;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(build_metric_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), n, nc[0], nc[1], ncells, d_vertices, d_xq, d_wq,
                      coef_lap, lap_layout, coef_mass, mass_layout, d_metric);
