@@ -55,6 +55,22 @@ def cpu_baseline(stfem, degree, r, sample_cells, threads):
                       f"OpenMP over 8 cell colours); deal.II unavailable, so not the reference binary"}
 
 
+def measured_traffic(kernel_name):
+    """HBM bytes per vmult from the committed rocprofv3 PMC passes of THIS command
+    (profiles/latest/traffic.json, written by tools/profile.sh): WRITE_SIZE + 2 x FETCH_SIZE,
+    the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None if the
+    profile does not belong to the kernel variant that ran."""
+    path = os.path.join(ROOT, "profiles", "latest", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("kernel") != kernel_name:
+            return None
+        return 1024.0 * (2.0 * t["fetch_kb_per_vmult"] + t["write_kb_per_vmult"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +218,9 @@ def main():
                        "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
                        "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(ctx.last_kernel_name)
+                         if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else None,
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

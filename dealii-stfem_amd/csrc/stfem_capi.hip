@@ -334,7 +334,7 @@ static int ensure_metric(stfem_ctx *c, bool use_lap, bool use_mass, hipStream_t 
 {
   static_assert(sizeof(double) == 8, "");
   const int n = c->p + 1;
-  const size_t nm = size_t(c->ncells) * 7 * n * n * n;
+  const size_t nm = size_t(c->ncells) * 8 * n * n * n;
   const int flags = (use_lap ? 1 : 0) | (use_mass ? 2 : 0);
   if (c->metric_valid && c->metric_flags == flags) return STFEM_OK;
   if (!c->d_vertices) {

@@ -143,7 +143,8 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
 // (include/operators.h:1135-1173) with unweighted S and collocation derivative D; the metric
 // terms  G = c_L w detJ J^-1 J^-T (6 entries)  and  Mq = c_M w detJ  come precomputed per
 // quadrature point from HBM (as deal.II's MatrixFree stores them), `met` = this cell's
-// [7][qz][qy][qx] block.  Six wave-private transposes instead of four: the x derivative lives in
+// [qz][qy][qx][8] block: one 64-byte record (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad) per point, read
+// with four 16-byte loads.  Six wave-private transposes instead of four: the x derivative lives in
 // layout A, the flux contraction needs all three gradient components at one point (layout B).
 template <int P, int NBM>
 __device__ __forceinline__ void
@@ -154,7 +155,6 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
   using G = Geometry<P, NBM>;
   constexpr int N = G::N;
   constexpr int CBS = G::CBS;
-  constexpr int N3 = N * N * N;
   double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
 
   // ---- A: interpolate x, y
@@ -234,11 +234,11 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
   }
   // metric terms are streamed one row (fixed y, all z) ahead; the empty asm statements keep the
   // compiler from hoisting every row's loads to the top (350 VGPRs of loads in flight)
-  double mrow[2][N][7];
+  double mrow[2][N][8];
   STFEM_UNROLL
   for (int z = 0; z < N; ++z)
     STFEM_UNROLL
-  for (int c = 0; c < 7; ++c) mrow[0][z][c] = met[c * N3 + z * N * N + 0 * N + k];
+  for (int c = 0; c < 8; ++c) mrow[0][z][c] = met[(z * N * N + 0 * N + k) * 8 + c];
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
     if (y + 1 < N) {
@@ -247,7 +247,7 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
       STFEM_UNROLL
       for (int z = 0; z < N; ++z)
         STFEM_UNROLL
-      for (int c = 0; c < 7; ++c) mrow[(y + 1) & 1][z][c] = mp[c * N3 + z * N * N + (y + 1) * N + k];
+      for (int c = 0; c < 8; ++c) mrow[(y + 1) & 1][z][c] = mp[(z * N * N + (y + 1) * N + k) * 8 + c];
     }
     double ur[N], gzr[N], fz[N], t[N];
     STFEM_UNROLL

@@ -24,7 +24,7 @@ struct SweepParams {
   int experiment;          // ablation bits for cell_core (256: no LDS traffic in the core); results wrong if set
   double eo_Si[EO_N], eo_L[EO_N]; // even-odd packed: interpolation (weights folded), 1D Laplacian
   // general-geometry path: plain interpolation S, collocation derivative D and D^T, and the
-  // per-quadrature-point metric [cell][7][qz][qy][qx] (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz, Mq)
+  // per-quadrature-point metric records [cell][qz][qy][qx][8] = (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad)
   double eo_S[EO_N], eo_Dq[EO_N], eo_DqT[EO_N];
   const double *metric;
 };
@@ -72,7 +72,7 @@ int launch_diagonal(const DiagParams &prm, void *stream);
 // Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm); returns 0 or -2.
 int tile_geometry(int p, int nbm, TilePlan &plan);
 int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);
-// fills metric[cell][7][q] from the vertex grid (device pointers); coef_* may be null,
+// fills metric[cell][q][8] from the vertex grid (device pointers); coef_* may be null,
 // layout 1 = per cell, 2 = per (cell, q)
 int launch_build_metric(int p, const int nc[3], const double *d_vertices, const double *d_xq,
                         const double *d_wq, const double *coef_lap, int lap_layout,

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(128) void diagonal_kernel(const DiagParams prm)
     if (con) continue;
     double v = 0.0;
     if (prm.metric) {
-      const double *m = prm.metric + cell * 7 * n3;
+      const double *m = prm.metric + cell * 8 * n3; // [q][8] records
       for (int qz = 0; qz < n; ++qz)
         for (int qy = 0; qy < n; ++qy)
           for (int qx = 0; qx < n; ++qx) {
@@ -119,9 +119,10 @@ __global__ __launch_bounds__(128) void diagonal_kernel(const DiagParams prm)
             const double sa = prm.S[qx * n + a], sb = prm.S[qy * n + b], sc = prm.S[qz * n + c];
             const double val = sa * sb * sc;
             const double g0 = prm.D[qx * n + a] * sb * sc, g1 = sa * prm.D[qy * n + b] * sc, g2 = sa * sb * prm.D[qz * n + c];
-            v += prm.ms * m[6 * n3 + q] * val * val +
-                 prm.ls * (m[q] * g0 * g0 + m[3 * n3 + q] * g1 * g1 + m[5 * n3 + q] * g2 * g2 +
-                           2.0 * (m[n3 + q] * g0 * g1 + m[2 * n3 + q] * g0 * g2 + m[4 * n3 + q] * g1 * g2));
+            const double *mq = m + q * 8;
+            v += prm.ms * mq[6] * val * val +
+                 prm.ls * (mq[0] * g0 * g0 + mq[3] * g1 * g1 + mq[5] * g2 * g2 +
+                           2.0 * (mq[1] * g0 * g1 + mq[2] * g0 * g2 + mq[4] * g1 * g2));
           }
     } else {
       const double fK = prm.vol * (prm.coef_lap ? prm.coef_lap[cell] : 1.0);

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
 
     if (GEN)
       cell_core_general<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM,
-                                prm.metric + (cell_xy + cells_per_layer * cz) * (7 * N * N * N), PA);
+                                prm.metric + (cell_xy + cells_per_layer * cz) * (8 * N * N * N), PA);
     else if (!(ex & 2))
       cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
     // the slab values have long arrived; consuming them here on every path keeps the compiler
@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
 }
 
 // Adds the halo partial sums of the lower y / z neighbours to the rows a tile owns on its y = 0
-// and z = 0 faces.  One workgroup per tile; rows are contiguous in x.
+// and z = 0 faces.  One workgroup per tile; 32 lanes per row (contiguous in x), 8 rows at a time,
+// no integer divisions in the loops.
 template <int P>
 __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, const TilePlan tp, int nbm)
 {
@@ -444,37 +445,38 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
   // owned local extents
   const int Xn = P * t.ncx + (t.last_x ? 1 : 0), Yn = P * t.ncy + (t.last_y ? 1 : 0),
             Zn = P * t.nlay + (t.last_z ? 1 : 0);
-  const int ys = has_y ? 1 : 0;
-  const int nfy = has_y ? Xn * Zn : 0;        // Y = 0, all X, Z
-  const int nfz = has_z ? Xn * (Yn - ys) : 0; // Z = 0, Y >= ys
+  const int X = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  if (X >= Xn) return;
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
-  for (int idx = threadIdx.x; idx < nfy + nfz; idx += blockDim.x) {
-    int X, Y, Z;
-    if (idx < nfy) {
-      Y = 0; X = idx % Xn; Z = idx / Xn;
-    } else {
-      const int q = idx - nfy;
-      Z = 0; X = q % Xn; Y = ys + q / Xn;
-    }
-    const int64_t g = int64_t(P) * t.cx0 + X + int64_t(prm.nx) * (int64_t(P) * t.cy0 + Y) +
-                      plane_stride * (int64_t(P) * t.cz0 + Z);
-    for (int j = 0; j < prm.nbo; ++j) {
-      double s = 0.0;
-      for (int dz = 0; dz <= (Z == 0 ? has_z : 0); ++dz)
-        for (int dy = 0; dy <= (Y == 0 ? has_y : 0); ++dy) {
-          if (!(dy | dz)) continue;
-          for (int dx = 0; dx <= (X == 0 ? has_x : 0); ++dx) {
-            const int nid = (t.tx - dx) + tp.ntx * ((t.ty - dy) + tp.nty * (t.tc - dz));
-            // the DoF in the neighbour's local coordinates (lower neighbours are never ragged
-            // in the direction they are lower in)
-            const int Xp = dx ? P * tp.cw : X, Zp = dz ? P * tp.lz : Z;
-            const int64_t base = int64_t(nid) * nbm + j;
-            if (dy) s += tp.yh[(base * tp.zp + Zp) * tp.tX + Xp];
-            else s += tp.zh[(base * tp.tY + Y) * tp.tX + Xp];
-          }
+  const int64_t g0 = int64_t(P) * t.cx0 + X + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
+                     plane_stride * (int64_t(P) * t.cz0);
+  const int dxn = (X == 0) ? has_x : 0; // the x = 0 column also collects from the tiles at tx - 1
+  const int XpL = P * tp.cw;            // that column in the left neighbour's coordinates
+  const int tid_y = id - tp.ntx, tid_z = id - tp.ntx * tp.nty, tid_yz = tid_z - tp.ntx;
+  for (int j = 0; j < prm.nbo; ++j) {
+    double *d = prm.dst[j] + g0;
+    const int64_t sy = tp.zp * tp.tX, sz = tp.tY * tp.tX;
+    const double *yh_y = tp.yh + (int64_t(tid_y) * nbm + j) * sy;   // (tx, ty-1, tc)
+    const double *yh_yz = tp.yh + (int64_t(tid_yz) * nbm + j) * sy; // (tx, ty-1, tc-1)
+    const double *zh_z = tp.zh + (int64_t(tid_z) * nbm + j) * sz;   // (tx, ty, tc-1)
+    // the same slabs of the tiles at tx - 1 (one tile earlier in the numbering)
+    const int64_t left_y = int64_t(nbm) * sy, left_z = int64_t(nbm) * sz;
+    if (has_y) // rows Y = 0, Z >= (has_z ? 1 : 0): contributions of the tiles below in y
+      for (int Z = rg + has_z; Z < Zn; Z += 8) {
+        double s = yh_y[Z * tp.tX + X];
+        if (dxn) s += (yh_y - left_y)[Z * tp.tX + XpL];
+        d[plane_stride * Z] += s;
+      }
+    if (has_z) // plane Z = 0: tiles below in z, and for its row Y = 0 also below in y
+      for (int Y = rg; Y < Yn; Y += 8) {
+        double s = zh_z[Y * tp.tX + X];
+        if (dxn) s += (zh_z - left_z)[Y * tp.tX + XpL];
+        if (Y == 0 && has_y) {
+          s += yh_y[X] + yh_yz[P * tp.lz * tp.tX + X];
+          if (dxn) s += (yh_y - left_y)[XpL] + (yh_yz - left_y)[P * tp.lz * tp.tX + XpL];
         }
-      prm.dst[j][g] += s;
-    }
+        d[int64_t(prm.nx) * Y] += s;
+      }
   }
 }
 
@@ -569,12 +571,13 @@ __global__ __launch_bounds__(256) void build_metric_kernel(int n, int ncx, int n
   const double JxW = det * wq[qx] * wq[qy] * wq[qz];
   const double fl = cl_layout == 0 ? 1.0 : (cl_layout == 1 ? cl[cell] : cl[gid]);
   const double fm = cm_layout == 0 ? 1.0 : (cm_layout == 1 ? cm[cell] : cm[gid]);
-  double *m = metric + cell * 7 * n3 + q;
+  double *m = metric + (cell * n3 + q) * 8; // one 64-byte record per quadrature point
   int comp = 0;
   for (int e = 0; e < 3; ++e)
     for (int f = e; f < 3; ++f, ++comp)
-      m[comp * n3] = fl * JxW * (Ji[e][0] * Ji[f][0] + Ji[e][1] * Ji[f][1] + Ji[e][2] * Ji[f][2]);
-  m[6 * n3] = fm * JxW;
+      m[comp] = fl * JxW * (Ji[e][0] * Ji[f][0] + Ji[e][1] * Ji[f][1] + Ji[e][2] * Ji[f][2]);
+  m[6] = fm * JxW;
+  m[7] = 0.0;
 }
 
 } // namespace
