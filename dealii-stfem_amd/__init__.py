@@ -32,7 +32,7 @@ class StfemError(RuntimeError):
 
 def build(force=False):
     """Compile libstfem_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)

@@ -40,7 +40,11 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   constexpr int N = G::N;
   constexpr int CBS = G::CBS;
   double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+#ifdef STFEM_ABLATION
   const bool no_lds = prm.experiment & 256;
+#else
+  constexpr bool no_lds = false;
+#endif
   if (no_lds) { in_active = false; out_active = false; }
 
   // ---- phase A: interpolate x, y (registers), hand over to layout B

@@ -27,6 +27,10 @@
 
 #include <cstdlib>
 
+#ifndef STFEM_TILE_P
+#define STFEM_TILE_P 0
+#endif
+
 namespace stfem {
 
 namespace {
@@ -136,7 +140,7 @@ __device__ __forceinline__ void wait_vmcnt(int n)
   else wait_vmcnt_imm<0>();
 }
 
-template <int P, int NBM, int MINW, bool ADD, bool COEF, bool GEN>
+template <int P, int NBM, int MINW, bool ADD, bool COEF, bool GEN, int COLOR>
 __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 {
   using TG = TileGeom<P, NBM>;
@@ -152,11 +156,11 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   double *lds = smem + wave * G::LDS_PER_WAVE;
 
   // tiles of this launch's x colour
-  const int ntxh = (tp.ntx - tp.xcolor + 1) / 2;
+  const int ntxh = (tp.ntx - COLOR + 1) / 2; // tiles of this launch's x colour
   const int nblocks = ntxh * tp.nty * tp.ntc;
   const int id = logical_block(blockIdx.x, nblocks);
   const TileCoords t =
-    tile_coords(prm, tp, 2 * (id % ntxh) + tp.xcolor, (id / ntxh) % tp.nty, id / (ntxh * tp.nty));
+    tile_coords(prm, tp, 2 * (id % ntxh) + COLOR, (id / ntxh) % tp.nty, id / (ntxh * tp.nty));
   const int tile_id = t.tx + tp.ntx * (t.ty + tp.nty * t.tc);
 
   const bool lane_ok = lane < G::ACTIVE;
@@ -197,7 +201,8 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   const int xext = P * t.ncx, yext = P * t.ncy;
   const int ymax = t.last_y ? yext + 1 : yext; // rows [0, ymax) go to dst, row yext to yh otherwise
   // x faces: odd tiles divert their shared columns to the x-slabs, even tiles collect them
-  const bool odd = tp.xcolor == 1;
+  constexpr bool odd = COLOR == 1;
+  const bool fast_tile = t.ncx == TG::CW && t.ncy == TG::ROWS && !t.last_y; // wave-uniform
   const bool collect_left = !odd && t.tx > 0, collect_right = !odd && !t.last_x;
   constexpr int XE = (2 * NBM * N * TY + 255) / 256; // slab values per thread and layer
   const int nrows = prm.nbo * N * TY;
@@ -213,7 +218,11 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   double PA[N * N];
   load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
   wait_vmcnt_imm<0>();
-  const int ex = tp.experiment;
+#ifdef STFEM_ABLATION
+  const int ex = tp.experiment; // timing experiments only (tools/ablate.sh); results are wrong
+#else
+  constexpr int ex = 0;
+#endif
   // stagger: the two workgroups of a CU start together with identical work and would otherwise
   // run their compute and their memory phases in lockstep; delaying the one in the odd wave slot
   // lets one stream while the other computes
@@ -353,6 +362,72 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     // Fully unrolled with predicates: with loops here the compiler drains the prefetch loads
     // above (s_waitcnt vmcnt(0)) before the first store.
     const int kend = last_layer ? N : P;
+    if (fast_tile && !(ex & 8)) {
+      // Full interior tile (the common case): all extents are compile-time constants, so the
+      // store phase is straight-line code: rows [0, P*ROWS) of every finished plane go to dst,
+      // row P*ROWS to the y-halo slab.
+      constexpr int XEXT = P * TG::CW, YMAX = P * TG::ROWS;
+      constexpr int NOF = (YMAX + 7) / 8;
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      const int hw = 2 * wave_u + (lane_s >> 5), X = lane_s & 31;
+      const bool x_lane = X <= XEXT;
+      const bool divert_lane = odd && (X == 0 || (X == XEXT && !t.last_x));
+      const unsigned lane_goff = X + prm.nx * (lane_s >> 5), lane_zoff = X + tp.tX * (lane_s >> 5);
+      const int lane_aoff = hw * TX + X;
+      double *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
+      STFEM_UNROLL
+      for (int j = 0; j < NBM; ++j) {
+        if (j >= prm.nbo) continue;
+        double sv[N][NOF];
+        STFEM_UNROLL
+        for (int kk = 0; kk < N; ++kk)
+          STFEM_UNROLL
+        for (int o = 0; o < NOF; ++o) {
+          const bool row_ok = (YMAX % 8 == 0) || hw + 8 * o < YMAX;
+          sv[kk][o] = ((kk < P || last_layer) && row_ok && x_lane) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : 0.0;
+        }
+        double *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u) + plane_stride * (int64_t(P) * layer);
+        double *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
+        STFEM_UNROLL
+        for (int kk = 0; kk < P; ++kk)
+          STFEM_UNROLL
+        for (int o = 0; o < NOF; ++o) {
+          const int Y = hw + 8 * o;
+          const bool row_ok = (YMAX % 8 == 0) || Y < YMAX;
+          if (row_ok && x_lane) {
+            double *d = dj + plane_stride * kk + int64_t(o * 8) * prm.nx + lane_goff;
+            if (odd && divert_lane) xs[kk * tp.tY + Y] = sv[kk][o];
+            else if (ADD) *d += sv[kk][o];
+            else *d = sv[kk][o];
+          }
+        }
+        if (last_layer) { // the top plane leaves too: to the z-halo slab, or to dst on the last chunk
+          double *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+          STFEM_UNROLL
+          for (int o = 0; o < NOF; ++o) {
+            const int Y = hw + 8 * o;
+            const bool row_ok = (YMAX % 8 == 0) || Y < YMAX;
+            if (row_ok && x_lane) {
+              double *d = dj + plane_stride * P + int64_t(o * 8) * prm.nx + lane_goff;
+              if (!t.last_z) (zj + o * 8 * tp.tX)[lane_zoff] = sv[P][o];
+              else if (odd && divert_lane) xs[P * tp.tY + Y] = sv[P][o];
+              else if (ADD) *d += sv[P][o];
+              else *d = sv[P][o];
+            }
+          }
+        }
+      }
+      // row Y = P*ROWS of every finished plane: to the y-halo slab (the tile is not last in y)
+      STFEM_UNROLL
+      for (int o = 0; o < (NBM * N + 7) / 8; ++o) {
+        const int r = hw + 8 * o;
+        const int j = r / kend, kk = r - j * kend;
+        if (r < prm.nbo * kend && x_lane)
+          tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + P * layer + kk) * tp.tX + X] =
+            acc[((j * N + kk) * TY + YMAX) * TX + X];
+      }
+    } else
     if (!(ex & 8)) {
       constexpr int NO = (TY + 7) / 8; // rows per half-wave and plane
       // store-phase lane roles: one slab row per half-wave (32 lanes, X = lane within the half).
@@ -490,19 +565,21 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
     const int nblocks = ntxh * tp.nty * tp.ntc;
     if (nblocks == 0) continue;
     const bool coef = prm.coef_lap || prm.coef_mass;
+#define STFEM_LAUNCH(WW, AA, CC, GG)                                                                        \
+  do {                                                                                                     \
+    if (colour == 1)                                                                                       \
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 1>), dim3(nblocks), dim3(256), 0, st, prm, tp); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 0>), dim3(nblocks), dim3(256), 0, st, prm, tp); \
+  } while (0)
     if (prm.metric) { // general geometry / per-q coefficients (baked into the metric)
-      if (tp.add)
-        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 1, true, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
-      else
-        hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, 1, false, false, true>), dim3(nblocks), dim3(256), 0, st, prm, tp);
-    } else if (tp.add && coef)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
-    else if (tp.add)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, true, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
-    else if (coef)
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, true, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
-    else
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WV, false, false, false>), dim3(nblocks), dim3(256), 0, st, prm, tp);
+      if (tp.add) STFEM_LAUNCH(1, true, false, true);
+      else STFEM_LAUNCH(1, false, false, true);
+    } else if (tp.add && coef) STFEM_LAUNCH(WV, true, true, false);
+    else if (tp.add) STFEM_LAUNCH(WV, true, false, false);
+    else if (coef) STFEM_LAUNCH(WV, false, true, false);
+    else STFEM_LAUNCH(WV, false, false, false);
+#undef STFEM_LAUNCH
     if (hipGetLastError() != hipSuccess) return -3;
   }
   if (tp.nty > 1 || tp.ntc > 1) {
@@ -520,6 +597,7 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
 
 } // namespace
 
+#if !STFEM_TILE_P
 namespace {
 
 // One thread per (cell, quadrature point): MappingQ1 Jacobian from the 8 cell vertices, then
@@ -611,23 +689,42 @@ int tile_geometry(int p, int nbm, TilePlan &plan)
   return 0;
 }
 
-int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream)
+#endif // !STFEM_TILE_P
+
+// The kernel templates are compiled once per degree (make builds this file with
+// -DSTFEM_TILE_P=1..4 in parallel); the translation unit without STFEM_TILE_P holds the common
+// host code and the dispatcher.
+#if STFEM_TILE_P
+#define STFEM_PASTE2(a, b) a##b
+#define STFEM_PASTE(a, b) STFEM_PASTE2(a, b)
+int STFEM_PASTE(launch_cart_tile_p, STFEM_TILE_P)(const SweepParams &prm, const TilePlan &plan, hipStream_t st)
 {
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const int nbm = round_nbm(prm.nbi > prm.nbo ? prm.nbi : prm.nbo);
-#define STFEM_CASE(PP, NB) \
-  if (p == PP && nbm == NB) return launch_tile_t<PP, NB>(prm, plan, st);
-#define STFEM_CASES(PP) \
-  STFEM_CASE(PP, 1) STFEM_CASE(PP, 2) STFEM_CASE(PP, 3) STFEM_CASE(PP, 4) STFEM_CASE(PP, 6) STFEM_CASE(PP, 8)
-  STFEM_CASES(1)
-  STFEM_CASES(2)
-  STFEM_CASES(3)
-  STFEM_CASES(4)
-#undef STFEM_CASES
+#define STFEM_CASE(NB) \
+  if (nbm == NB) return launch_tile_t<STFEM_TILE_P, NB>(prm, plan, st);
+  STFEM_CASE(1) STFEM_CASE(2) STFEM_CASE(3) STFEM_CASE(4) STFEM_CASE(6) STFEM_CASE(8)
 #undef STFEM_CASE
   return -2;
 }
+#else
+int launch_cart_tile_p1(const SweepParams &, const TilePlan &, hipStream_t);
+int launch_cart_tile_p2(const SweepParams &, const TilePlan &, hipStream_t);
+int launch_cart_tile_p3(const SweepParams &, const TilePlan &, hipStream_t);
+int launch_cart_tile_p4(const SweepParams &, const TilePlan &, hipStream_t);
+
+int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream)
+{
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (p) {
+    case 1: return launch_cart_tile_p1(prm, plan, st);
+    case 2: return launch_cart_tile_p2(prm, plan, st);
+    case 3: return launch_cart_tile_p3(prm, plan, st);
+    case 4: return launch_cart_tile_p4(prm, plan, st);
+    default: return -2;
+  }
+}
 
 const char *cart_tile_name(int, int) { return "st_sweep_cart_tile"; }
+#endif
 
 } // namespace stfem
