@@ -447,6 +447,7 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
         tp.add = (add || !first) ? 1 : 0;
         tp.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
         tp.stagger = getenv("STFEM_STAGGER") ? atoi(getenv("STFEM_STAGGER")) : 0;
+        tp.stagger_div = getenv("STFEM_STAGGER_DIV") ? std::max(1, atoi(getenv("STFEM_STAGGER_DIV"))) : 256;
         rc = launch_cart_tile(c->p, prm, tp, st);
         c->last_kernel = cart_tile_name(c->p, nbm);
       }

@@ -43,7 +43,8 @@ struct TilePlan {
   double *xl, *xr;   // x-face slabs of odd tiles: [tile][block][zl][Y] (their X = 0 / X = xext columns)
   int add;           // accumulate into dst instead of overwriting
   int xcolor;        // parity of the tile x-index handled by this launch
-  int stagger;       // start delay of the workgroup in the odd wave slot, units of 1024 cycles
+  int stagger;       // start delay (units of 1024 cycles) of every other group of stagger_div blocks
+  int stagger_div;
   int experiment;    // ablation bit mask (STFEM_EXP; results are wrong when nonzero): 1 no src loads,
                      // 2 no cell core, 4 no LDS accumulation, 8 no store phase
 };

@@ -219,16 +219,18 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
   wait_vmcnt_imm<0>();
 #ifdef STFEM_ABLATION
+#define STFEM_LAYER_BARRIER() do { if (!(ex & 2048)) __syncthreads(); } while (0)
   const int ex = tp.experiment; // timing experiments only (tools/ablate.sh); results are wrong
 #else
+#define STFEM_LAYER_BARRIER() __syncthreads()
   constexpr int ex = 0;
 #endif
   // stagger: the two workgroups of a CU start together with identical work and would otherwise
   // run their compute and their memory phases in lockstep; delaying the one in the odd wave slot
   // lets one stream while the other computes
   if (tp.stagger > 0) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
-    if (hwid & 1)
+    // key: which of the co-resident workgroups of a CU this is (first round of the dispatch)
+    if ((blockIdx.x / tp.stagger_div) & 1)
       for (int i = 0; i < tp.stagger; ++i) __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles each
   }
 
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         if (constrained<P>(pm, y, x)) PA[y * N + x] = 0.0;
     }
 
-    __syncthreads(); // all waves are done with the transpose slabs: the region becomes `acc`
+    STFEM_LAYER_BARRIER(); // all waves are done with the transpose slabs: the region becomes `acc`
 
     // owner lanes initialise their DoFs
     if (out_active && !(ex & 4)) {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
     // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
     if (!last_layer && !(ex & 1)) load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA);
-    __syncthreads();
+    STFEM_LAYER_BARRIER();
 
     // stream the finished planes to their destination: k = 0..P-1, and k = P on the last layer.
     // Fully unrolled with predicates: with loops here the compiler drains the prefetch loads
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         if (e < prm.nbo * PLANE) carry[m] = acc[(j * (N - 1) + P) * PLANE + e];
       }
     }
-    __syncthreads(); // slab free again for the next layer's transposes
+    STFEM_LAYER_BARRIER(); // slab free again for the next layer's transposes
     // the prefetched planes must have landed before PA is touched; the stores issued after
     // them may stay in flight.  Lower bound of the stores this wave has issued since: one per
     // (block, plane, row group) whose first half-wave row exists.

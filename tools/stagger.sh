@@ -1,4 +1,6 @@
 #!/bin/bash
-for s in ${@:-0 2 4 6 8 12}; do
-  echo -n "STFEM_STAGGER=$s "; STFEM_STAGGER=$s python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | grep -o '"kernel_ms": [0-9.]*'
+# usage: tools/stagger.sh <div> s1 s2 ...
+D=$1; shift
+for s in "$@"; do
+  echo -n "DIV=$D STAGGER=$s "; STFEM_STAGGER_DIV=$D STFEM_STAGGER=$s python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | grep -o '"kernel_ms": [0-9.]*'
 done
