@@ -46,7 +46,8 @@ class _MeshDesc(C.Structure):
 
 
 class _SpaceDesc(C.Structure):
-    _fields_ = [("degree", C.c_int32), ("n_q_points_1d", C.c_int32), ("n_components", C.c_int32)]
+    _fields_ = [("degree", C.c_int32), ("n_q_points_1d", C.c_int32), ("n_components", C.c_int32),
+                ("precision", C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -60,6 +61,7 @@ SIGNATURES = {
     "stfem_n_dofs": (C.c_int64, [_vp]),
     "stfem_n_cells": (C.c_int64, [_vp]),
     "stfem_is_cartesian": (C.c_int, [_vp]),
+    "stfem_ctx_precision": (C.c_int, [_vp]),
     "stfem_set_coefficient": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "stfem_vector_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "stfem_vector_wrap": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -208,7 +210,8 @@ class MatrixFreeOperator:
     """Context = MatrixFree + MatrixFreeOperator state of one rank (operators.h:967-1191)."""
 
     def __init__(self, degree, ncell, vertices=None, lower=(0, 0, 0), upper=(1, 1, 1),
-                 dirichlet_mask=63, device=0, mass_matrix_scaling=0.0, laplace_matrix_scaling=0.0):
+                 dirichlet_mask=63, device=0, mass_matrix_scaling=0.0, laplace_matrix_scaling=0.0,
+                 number="double"):
         self.degree = degree
         self.ncell = tuple(int(v) for v in ncell)
         self.mass_matrix_scaling = mass_matrix_scaling
@@ -224,7 +227,9 @@ class MatrixFreeOperator:
         m.upper[:] = upper
         m.dirichlet_mask = dirichlet_mask
         m.device = device
-        s = _SpaceDesc(degree, degree + 1, 1)
+        assert number in ("double", "float")  # the operator's Number template argument
+        self.number = number
+        s = _SpaceDesc(degree, degree + 1, 1, 1 if number == "float" else 0)
         h = _vp()
         _check(lib().stfem_ctx_create(C.byref(m), C.byref(s), C.byref(h)), "stfem_ctx_create")
         self._h = h

@@ -16,6 +16,43 @@
 
 using namespace stfem;
 
+// Precision traits: the same host logic drives the fp64 (stfem::f64) and fp32 (stfem::f32)
+// instantiations of the device code.
+struct Prec64 {
+  using real = double;
+  using Sweep = f64::SweepParams;
+  using Plan = f64::TilePlan;
+  using Diag = f64::DiagParams;
+  static int atomic(int p, const Sweep &s, void *st) { return f64::launch_cart_atomic(p, s, st); }
+  static int geometry(int p, int nbm, Plan &pl) { return f64::tile_geometry(p, nbm, pl); }
+  static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f64::launch_cart_tile(p, s, pl, st); }
+  static int diagonal(const Diag &d, void *st) { return f64::launch_diagonal(d, st); }
+  static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
+                    int ll, const real *cm, int ml, real *m, void *st)
+  {
+    return f64::launch_build_metric(p, nc, v, xq, wq, cl, ll, cm, ml, m, st);
+  }
+  static const char *tile_name() { return "st_sweep_cart_tile<f64>"; }
+  static const char *atomic_name() { return "st_sweep_cart_atomic<f64>"; }
+};
+struct Prec32 {
+  using real = float;
+  using Sweep = f32::SweepParams;
+  using Plan = f32::TilePlan;
+  using Diag = f32::DiagParams;
+  static int atomic(int p, const Sweep &s, void *st) { return f32::launch_cart_atomic(p, s, st); }
+  static int geometry(int p, int nbm, Plan &pl) { return f32::tile_geometry(p, nbm, pl); }
+  static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f32::launch_cart_tile(p, s, pl, st); }
+  static int diagonal(const Diag &d, void *st) { return f32::launch_diagonal(d, st); }
+  static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
+                    int ll, const real *cm, int ml, real *m, void *st)
+  {
+    return f32::launch_build_metric(p, nc, v, xq, wq, cl, ll, cm, ml, m, st);
+  }
+  static const char *tile_name() { return "st_sweep_cart_tile<f32>"; }
+  static const char *atomic_name() { return "st_sweep_cart_atomic<f32>"; }
+};
+
 namespace {
 
 thread_local std::string g_hip_error;
@@ -42,16 +79,19 @@ struct stfem_ctx {
   double lower[3] = {0, 0, 0}, h[3] = {1, 1, 1};
   ShapeTables tab;
   std::vector<double> vertices; // host copy (general meshes)
-  double *d_coef[2] = {nullptr, nullptr}; // [0] mass, [1] laplace
+  int prec = 0;                // 0 = fp64, 1 = fp32 (element type of vectors, coefficients, metric)
+  size_t es = sizeof(double);  // element size
+  void *d_coef[2] = {nullptr, nullptr}; // [0] mass, [1] laplace
   int coef_layout[2] = {0, 0};
-  double *d_scratch = nullptr; // reductions
+  double *d_scratch = nullptr; // reductions (always double)
   const char *last_kernel = "";
   // tile variant: halo slabs (grown on demand)
-  double *d_halo = nullptr;
-  size_t halo_doubles = 0;
+  void *d_halo = nullptr;
+  size_t halo_doubles = 0; // elements
   int variant = 0; // 0 = tile (default), 1 = atomic
   // general-geometry path: device copies of vertices and the 1D rule, metric terms per (cell, q)
-  double *d_vertices = nullptr, *d_rule = nullptr, *d_metric = nullptr;
+  double *d_vertices = nullptr, *d_rule = nullptr;
+  void *d_metric = nullptr;
   bool metric_valid = false;
   int metric_flags = -1; // which coefficients are baked into d_metric (bit0 laplace, bit1 mass)
 };
@@ -60,7 +100,7 @@ struct stfem_vec {
   stfem_ctx *ctx = nullptr;
   int nb = 0;
   bool owns = false;
-  std::vector<double *> blk;
+  std::vector<void *> blk; // device arrays of the context's element type
 };
 
 extern "C" {
@@ -89,6 +129,7 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
   if (space->degree < 1 || space->degree > 4) return STFEM_ERR_UNSUPPORTED;
   if (space->n_q_points_1d != space->degree + 1 || space->n_components != 1)
     return STFEM_ERR_UNSUPPORTED;
+  if (space->precision != 0 && space->precision != 1) return STFEM_ERR_UNSUPPORTED;
   for (int d = 0; d < 3; ++d)
     if (mesh->ncell[d] < 1) return STFEM_ERR_INVALID_ARGUMENT;
   int ndev = 0;
@@ -99,6 +140,8 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
   stfem_ctx *c = new (std::nothrow) stfem_ctx;
   if (!c) return STFEM_ERR_OUT_OF_MEMORY;
   c->p = space->degree;
+  c->prec = space->precision;
+  c->es = c->prec ? sizeof(float) : sizeof(double);
   c->device = mesh->device;
   c->ndofs = c->ncells = 1;
   for (int d = 0; d < 3; ++d) {
@@ -165,7 +208,7 @@ void stfem_ctx_destroy(stfem_ctx *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (double *&p : c->d_coef)
+  for (void *&p : c->d_coef)
     if (p) (void)hipFree(p);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_halo) (void)hipFree(c->d_halo);
@@ -178,6 +221,7 @@ void stfem_ctx_destroy(stfem_ctx *c)
 int64_t stfem_n_dofs(const stfem_ctx *c) { return c ? c->ndofs : 0; }
 int64_t stfem_n_cells(const stfem_ctx *c) { return c ? c->ncells : 0; }
 int stfem_is_cartesian(const stfem_ctx *c) { return c && c->cartesian ? 1 : 0; }
+int stfem_ctx_precision(const stfem_ctx *c) { return c ? c->prec : -1; }
 const char *stfem_last_kernel_name(const stfem_ctx *c) { return c ? c->last_kernel : ""; }
 
 int stfem_set_coefficient(stfem_ctx *c, int which, int layout, const double *host)
@@ -194,8 +238,13 @@ int stfem_set_coefficient(stfem_ctx *c, int which, int layout, const double *hos
   if (!host) return STFEM_ERR_INVALID_ARGUMENT;
   const int nq = c->p + 1;
   const size_t n = size_t(c->ncells) * (layout == 2 ? size_t(nq) * nq * nq : 1);
-  if (hipMalloc(&c->d_coef[which], n * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
-  HIP_TRY(hipMemcpy(c->d_coef[which], host, n * sizeof(double), hipMemcpyHostToDevice));
+  if (hipMalloc(&c->d_coef[which], n * c->es) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+  if (c->prec) {
+    std::vector<float> tmp(host, host + n);
+    HIP_TRY(hipMemcpy(c->d_coef[which], tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(c->d_coef[which], host, n * sizeof(double), hipMemcpyHostToDevice));
+  }
   c->coef_layout[which] = layout;
   return STFEM_OK;
 }
@@ -213,11 +262,11 @@ int stfem_vector_create(stfem_ctx *c, int nb, stfem_vec **out)
   v->owns = true;
   v->blk.assign(nb, nullptr);
   for (int b = 0; b < nb; ++b) {
-    if (hipMalloc(&v->blk[b], size_t(c->ndofs) * sizeof(double)) != hipSuccess) {
+    if (hipMalloc(&v->blk[b], size_t(c->ndofs) * c->es) != hipSuccess) {
       stfem_vector_destroy(v);
       return STFEM_ERR_OUT_OF_MEMORY;
     }
-    if (hipMemset(v->blk[b], 0, size_t(c->ndofs) * sizeof(double)) != hipSuccess) {
+    if (hipMemset(v->blk[b], 0, size_t(c->ndofs) * c->es) != hipSuccess) {
       stfem_vector_destroy(v);
       return STFEM_ERR_HIP;
     }
@@ -239,7 +288,7 @@ int stfem_vector_wrap(stfem_ctx *c, int nb, void *const *blocks, stfem_vec **out
       delete v;
       return STFEM_ERR_INVALID_ARGUMENT;
     }
-    v->blk.push_back(static_cast<double *>(blocks[b]));
+    v->blk.push_back(blocks[b]);
   }
   *out = v;
   return STFEM_OK;
@@ -250,7 +299,7 @@ void stfem_vector_destroy(stfem_vec *v)
   if (!v) return;
   if (v->owns) {
     (void)hipSetDevice(v->ctx->device);
-    for (double *p : v->blk)
+    for (void *p : v->blk)
       if (p) (void)hipFree(p);
   }
   delete v;
@@ -266,8 +315,16 @@ int stfem_vector_upload(stfem_vec *v, const double *const *host)
 {
   if (!v || !host) return STFEM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(v->ctx->device));
-  for (int b = 0; b < v->nb; ++b)
-    HIP_TRY(hipMemcpy(v->blk[b], host[b], size_t(v->ctx->ndofs) * sizeof(double), hipMemcpyHostToDevice));
+  const size_t n = size_t(v->ctx->ndofs);
+  std::vector<float> tmp(v->ctx->prec ? n : 0);
+  for (int b = 0; b < v->nb; ++b) {
+    if (v->ctx->prec) { // host side is always double; fp32 contexts convert here
+      for (size_t i = 0; i < n; ++i) tmp[i] = float(host[b][i]);
+      HIP_TRY(hipMemcpy(v->blk[b], tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      HIP_TRY(hipMemcpy(v->blk[b], host[b], n * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   return STFEM_OK;
 }
 
@@ -276,35 +333,47 @@ int stfem_vector_download(const stfem_vec *v, double *const *host)
   if (!v || !host) return STFEM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(v->ctx->device));
   HIP_TRY(hipDeviceSynchronize());
-  for (int b = 0; b < v->nb; ++b)
-    HIP_TRY(hipMemcpy(host[b], v->blk[b], size_t(v->ctx->ndofs) * sizeof(double), hipMemcpyDeviceToHost));
+  const size_t n = size_t(v->ctx->ndofs);
+  std::vector<float> tmp(v->ctx->prec ? n : 0);
+  for (int b = 0; b < v->nb; ++b) {
+    if (v->ctx->prec) {
+      HIP_TRY(hipMemcpy(tmp.data(), v->blk[b], n * sizeof(float), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) host[b][i] = tmp[i];
+    } else {
+      HIP_TRY(hipMemcpy(host[b], v->blk[b], n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+  }
   return STFEM_OK;
 }
 
 // ------------------------------------------------------------------------------------ operator
 
-static void fill_common(const stfem_ctx *c, SweepParams &prm)
+extern "C++" {
+template <class PR> static void fill_common(const stfem_ctx *c, typename PR::Sweep &prm)
 {
+  using real = typename PR::real;
   std::memset(&prm, 0, sizeof(prm));
   prm.ncx = c->nc[0]; prm.ncy = c->nc[1]; prm.ncz = c->nc[2];
   prm.nx = c->nd[0]; prm.ny = c->nd[1]; prm.nz = c->nd[2];
   prm.ncells = c->ncells;
   prm.dmask = c->dmask;
-  prm.vol = c->h[0] * c->h[1] * c->h[2];
-  prm.ihx2 = 1.0 / (c->h[0] * c->h[0]);
-  prm.ihy2 = 1.0 / (c->h[1] * c->h[1]);
-  prm.ihz2 = 1.0 / (c->h[2] * c->h[2]);
+  prm.vol = real(c->h[0] * c->h[1] * c->h[2]);
+  prm.ihx2 = real(1.0 / (c->h[0] * c->h[0]));
+  prm.ihy2 = real(1.0 / (c->h[1] * c->h[1]));
+  prm.ihz2 = real(1.0 / (c->h[2] * c->h[2]));
   const int ne = eo_size(c->p + 1);
-  std::memcpy(prm.eo_Si, c->tab.eo_Si, ne * sizeof(double));
-  std::memcpy(prm.eo_L, c->tab.eo_L, ne * sizeof(double));
-  std::memcpy(prm.eo_S, c->tab.eo_S, ne * sizeof(double));
-  std::memcpy(prm.eo_Dq, c->tab.eo_Dq, ne * sizeof(double));
-  std::memcpy(prm.eo_DqT, c->tab.eo_DqT, ne * sizeof(double));
+  for (int i = 0; i < ne; ++i) {
+    prm.eo_Si[i] = real(c->tab.eo_Si[i]);
+    prm.eo_L[i] = real(c->tab.eo_L[i]);
+    prm.eo_S[i] = real(c->tab.eo_S[i]);
+    prm.eo_Dq[i] = real(c->tab.eo_Dq[i]);
+    prm.eo_DqT[i] = real(c->tab.eo_DqT[i]);
+  }
 }
 
 // Chooses the z-chunking of the tile variant: enough workgroups to fill 2 per CU several times
 // over, chunks long enough that the z-halo stays small.
-static void plan_chunks(const stfem_ctx *c, TilePlan &tp)
+template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp)
 {
   tp.ntx = (c->nc[0] + tp.cw - 1) / tp.cw;
   tp.nty = (c->nc[1] + tp.rows - 1) / tp.rows;
@@ -330,9 +399,9 @@ static void plan_chunks(const stfem_ctx *c, TilePlan &tp)
 // (Re)builds the per-quadrature-point metric of the general path.  The coefficients in force
 // (operators.h:1152-1162: a coefficient replaces the scaling) are baked in; the flags record
 // which of them were used so that a K-only / M-only apply with a different set rebuilds.
-static int ensure_metric(stfem_ctx *c, bool use_lap, bool use_mass, hipStream_t st)
+template <class PR> static int ensure_metric(stfem_ctx *c, bool use_lap, bool use_mass, hipStream_t st)
 {
-  static_assert(sizeof(double) == 8, "");
+  using real = typename PR::real;
   const int n = c->p + 1;
   const size_t nm = size_t(c->ncells) * 8 * n * n * n;
   const int flags = (use_lap ? 1 : 0) | (use_mass ? 2 : 0);
@@ -357,12 +426,12 @@ static int ensure_metric(stfem_ctx *c, bool use_lap, bool use_mass, hipStream_t 
     if (hipMalloc(&c->d_rule, rule.size() * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
     HIP_TRY(hipMemcpy(c->d_rule, rule.data(), rule.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  if (!c->d_metric && hipMalloc(&c->d_metric, nm * sizeof(double)) != hipSuccess)
+  if (!c->d_metric && hipMalloc(&c->d_metric, nm * sizeof(real)) != hipSuccess)
     return STFEM_ERR_OUT_OF_MEMORY;
-  const int rc = launch_build_metric(c->p, c->nc, c->d_vertices, c->d_rule, c->d_rule + n,
-                                     use_lap ? c->d_coef[1] : nullptr, use_lap ? c->coef_layout[1] : 0,
-                                     use_mass ? c->d_coef[0] : nullptr, use_mass ? c->coef_layout[0] : 0,
-                                     c->d_metric, st);
+  const int rc = PR::metric(c->p, c->nc, c->d_vertices, c->d_rule, c->d_rule + n,
+                            use_lap ? static_cast<const real *>(c->d_coef[1]) : nullptr, use_lap ? c->coef_layout[1] : 0,
+                            use_mass ? static_cast<const real *>(c->d_coef[0]) : nullptr, use_mass ? c->coef_layout[0] : 0,
+                            static_cast<real *>(c->d_metric), st);
   if (rc != 0) return hip_fail(hipGetLastError(), "build_metric");
   c->metric_valid = true;
   c->metric_flags = flags;
@@ -370,10 +439,12 @@ static int ensure_metric(stfem_ctx *c, bool use_lap, bool use_mass, hipStream_t 
 }
 
 // a(j,i), b(j,i): effective nbo x nbi matrices (row-major)
-static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,
+template <class PR>
+static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,
                        const std::vector<double> &b, stfem_vec *dst, const stfem_vec *src, int add,
                        bool use_lap_coef, bool use_mass_coef, void *stream)
 {
+  using real = typename PR::real;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int j = 0; j < nbo; ++j)
@@ -382,20 +453,20 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
   // general path: non-Cartesian cells or per-quadrature-point coefficients -> metric terms
   const bool general = !c->cartesian || c->coef_layout[0] == 2 || c->coef_layout[1] == 2;
   if (general) {
-    const int rc = ensure_metric(c, use_lap_coef, use_mass_coef, st);
+    const int rc = ensure_metric<PR>(c, use_lap_coef, use_mass_coef, st);
     if (rc != STFEM_OK) return rc;
   }
   const bool atomic = c->variant == 1 && !general;
   if (!add && atomic)
     for (int j = 0; j < nbo; ++j)
-      HIP_TRY(hipMemsetAsync(dst->blk[j], 0, size_t(c->ndofs) * sizeof(double), st));
-  SweepParams prm;
-  fill_common(c, prm);
-  prm.coef_lap = (use_lap_coef && !general) ? c->d_coef[1] : nullptr;
-  prm.coef_mass = (use_mass_coef && !general) ? c->d_coef[0] : nullptr;
+      HIP_TRY(hipMemsetAsync(dst->blk[j], 0, size_t(c->ndofs) * sizeof(real), st));
+  typename PR::Sweep prm;
+  fill_common<PR>(c, prm);
+  prm.coef_lap = (use_lap_coef && !general) ? static_cast<const real *>(c->d_coef[1]) : nullptr;
+  prm.coef_mass = (use_mass_coef && !general) ? static_cast<const real *>(c->d_coef[0]) : nullptr;
   if (general) {
-    prm.metric = c->d_metric;
-    prm.vol = 1.0; // detJ and the weights live in the metric
+    prm.metric = static_cast<const real *>(c->d_metric);
+    prm.vol = real(1); // detJ and the weights live in the metric
   }
   prm.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
   for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS) {
@@ -405,9 +476,9 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
       bool nonzero = false;
       for (int j = 0; j < tj; ++j)
         for (int i = 0; i < ti; ++i) {
-          prm.alpha[j * ti + i] = a[size_t(j0 + j) * nbi + i0 + i];
-          prm.beta[j * ti + i] = b[size_t(j0 + j) * nbi + i0 + i];
-          nonzero = nonzero || prm.alpha[j * ti + i] != 0.0 || prm.beta[j * ti + i] != 0.0;
+          prm.alpha[j * ti + i] = real(a[size_t(j0 + j) * nbi + i0 + i]);
+          prm.beta[j * ti + i] = real(b[size_t(j0 + j) * nbi + i0 + i]);
+          nonzero = nonzero || prm.alpha[j * ti + i] != real(0) || prm.beta[j * ti + i] != real(0);
         }
       // the reference skips exact zeros too (operators.h:551,556); a panel may only be skipped
       // if something else still defines dst
@@ -415,17 +486,17 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
       if (!nonzero && (atomic || add || !first || !last_panel)) continue;
       prm.nbo = tj;
       prm.nbi = ti;
-      for (int j = 0; j < tj; ++j) prm.dst[j] = dst->blk[j0 + j];
-      for (int i = 0; i < ti; ++i) prm.src[i] = src->blk[i0 + i];
+      for (int j = 0; j < tj; ++j) prm.dst[j] = static_cast<real *>(dst->blk[j0 + j]);
+      for (int i = 0; i < ti; ++i) prm.src[i] = static_cast<const real *>(src->blk[i0 + i]);
       int rc;
       if (atomic) {
-        rc = launch_cart_atomic(c->p, prm, st);
-        c->last_kernel = cart_atomic_name(c->p, std::max(tj, ti));
+        rc = PR::atomic(c->p, prm, st);
+        c->last_kernel = PR::atomic_name();
       } else {
-        TilePlan tp;
+        typename PR::Plan tp;
         std::memset(&tp, 0, sizeof(tp));
         const int nbm = std::max(tj, ti);
-        if (tile_geometry(c->p, nbm, tp) != 0) return STFEM_ERR_UNSUPPORTED;
+        if (PR::geometry(c->p, nbm, tp) != 0) return STFEM_ERR_UNSUPPORTED;
         plan_chunks(c, tp);
         const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
         const size_t ntiles = size_t(tp.ntx) * tp.nty * tp.ntc;
@@ -436,20 +507,20 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
           if (c->d_halo) HIP_TRY(hipFree(c->d_halo));
           c->d_halo = nullptr;
           c->halo_doubles = 0;
-          if (hipMalloc(&c->d_halo, (nyh + nzh + 2 * nxs) * sizeof(double)) != hipSuccess)
+          if (hipMalloc(&c->d_halo, (nyh + nzh + 2 * nxs) * sizeof(real)) != hipSuccess)
             return STFEM_ERR_OUT_OF_MEMORY;
           c->halo_doubles = nyh + nzh + 2 * nxs;
         }
-        tp.yh = c->d_halo;
-        tp.zh = c->d_halo + nyh;
+        tp.yh = static_cast<real *>(c->d_halo);
+        tp.zh = tp.yh + nyh;
         tp.xl = tp.zh + nzh;
         tp.xr = tp.xl + nxs;
         tp.add = (add || !first) ? 1 : 0;
         tp.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
         tp.stagger = getenv("STFEM_STAGGER") ? atoi(getenv("STFEM_STAGGER")) : 0;
         tp.stagger_div = getenv("STFEM_STAGGER_DIV") ? std::max(1, atoi(getenv("STFEM_STAGGER_DIV"))) : 256;
-        rc = launch_cart_tile(c->p, prm, tp, st);
-        c->last_kernel = cart_tile_name(c->p, nbm);
+        rc = PR::tile(c->p, prm, tp, st);
+        c->last_kernel = PR::tile_name();
       }
       if (rc == -3) return hip_fail(hipGetLastError(), "kernel launch");
       if (rc != 0) return STFEM_ERR_UNSUPPORTED;
@@ -457,6 +528,16 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
     }
   }
   return STFEM_OK;
+}
+
+} // extern "C++"
+
+static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a, const std::vector<double> &b,
+                       stfem_vec *dst, const stfem_vec *src, int add, bool use_lap_coef, bool use_mass_coef,
+                       void *stream)
+{
+  return c->prec ? apply_tiled_t<Prec32>(c, nbo, nbi, a, b, dst, src, add, use_lap_coef, use_mass_coef, stream)
+                 : apply_tiled_t<Prec64>(c, nbo, nbi, a, b, dst, src, add, use_lap_coef, use_mass_coef, stream);
 }
 
 int stfem_st_vmult(stfem_ctx *c, int nrows, int ncols, const double *alpha, const double *beta,
@@ -491,8 +572,10 @@ int stfem_space_vmult(stfem_ctx *c, double ms, double ls, stfem_vec *dst, const 
   return apply_tiled(c, 1, 1, a, b, dst, src, 0, lc, mc, stream);
 }
 
-int stfem_diagonal(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *stream)
+extern "C++" {
+template <class PR> static int diagonal_t(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *stream)
 {
+  using real = typename PR::real;
   if (!c || !diag || diag->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
   if (diag->nb != 1) return STFEM_ERR_SHAPE_MISMATCH;
   HIP_TRY(hipSetDevice(c->device));
@@ -500,29 +583,29 @@ int stfem_diagonal(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *st
   const bool lc = ls != 0.0 && c->coef_layout[1] != 0, mc = ms != 0.0 && c->coef_layout[0] != 0;
   const bool general = !c->cartesian || c->coef_layout[0] == 2 || c->coef_layout[1] == 2;
   if (general) {
-    const int rc = ensure_metric(c, lc, mc, st);
+    const int rc = ensure_metric<PR>(c, lc, mc, st);
     if (rc != STFEM_OK) return rc;
   }
-  HIP_TRY(hipMemsetAsync(diag->blk[0], 0, size_t(c->ndofs) * sizeof(double), st));
-  DiagParams prm;
+  HIP_TRY(hipMemsetAsync(diag->blk[0], 0, size_t(c->ndofs) * sizeof(real), st));
+  typename PR::Diag prm;
   std::memset(&prm, 0, sizeof(prm));
-  prm.diag = diag->blk[0];
+  prm.diag = static_cast<real *>(diag->blk[0]);
   prm.ncx = c->nc[0]; prm.ncy = c->nc[1]; prm.ncz = c->nc[2];
   prm.nx = c->nd[0]; prm.ny = c->nd[1];
   prm.p = c->p;
   prm.dmask = c->dmask;
-  prm.ms = ms != 0.0 ? (mc ? 1.0 : ms) : 0.0; // operators.h:1152-1162
-  prm.ls = ls != 0.0 ? (lc ? 1.0 : ls) : 0.0;
-  prm.vol = c->h[0] * c->h[1] * c->h[2];
-  prm.ihx2 = 1.0 / (c->h[0] * c->h[0]);
-  prm.ihy2 = 1.0 / (c->h[1] * c->h[1]);
-  prm.ihz2 = 1.0 / (c->h[2] * c->h[2]);
+  prm.ms = real(ms != 0.0 ? (mc ? 1.0 : ms) : 0.0); // operators.h:1152-1162
+  prm.ls = real(ls != 0.0 ? (lc ? 1.0 : ls) : 0.0);
+  prm.vol = real(c->h[0] * c->h[1] * c->h[2]);
+  prm.ihx2 = real(1.0 / (c->h[0] * c->h[0]));
+  prm.ihy2 = real(1.0 / (c->h[1] * c->h[1]));
+  prm.ihz2 = real(1.0 / (c->h[2] * c->h[2]));
   const int n = c->p + 1;
   if (general) {
-    prm.metric = c->d_metric;
+    prm.metric = static_cast<const real *>(c->d_metric);
   } else {
-    prm.coef_lap = lc ? c->d_coef[1] : nullptr;
-    prm.coef_mass = mc ? c->d_coef[0] : nullptr;
+    prm.coef_lap = lc ? static_cast<const real *>(c->d_coef[1]) : nullptr;
+    prm.coef_mass = mc ? static_cast<const real *>(c->d_coef[0]) : nullptr;
   }
   for (int a = 0; a < n; ++a) {
     double m = 0, l = 0;
@@ -530,41 +613,64 @@ int stfem_diagonal(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *st
       m += c->tab.wq[q] * c->tab.S[q * n + a] * c->tab.S[q * n + a];
       l += c->tab.wq[q] * c->tab.D[q * n + a] * c->tab.D[q * n + a];
     }
-    prm.m1[a] = m;
-    prm.l1[a] = l;
+    prm.m1[a] = real(m);
+    prm.l1[a] = real(l);
   }
   for (int i = 0; i < n * n; ++i) {
-    prm.S[i] = c->tab.S[i];
-    prm.D[i] = c->tab.D[i];
+    prm.S[i] = real(c->tab.S[i]);
+    prm.D[i] = real(c->tab.D[i]);
   }
-  if (launch_diagonal(prm, st) != 0) return hip_fail(hipGetLastError(), "diagonal launch");
+  if (PR::diagonal(prm, st) != 0) return hip_fail(hipGetLastError(), "diagonal launch");
   return STFEM_OK;
+}
+
+} // extern "C++"
+
+int stfem_diagonal(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *stream)
+{
+  if (!c) return STFEM_ERR_INVALID_ARGUMENT;
+  return c->prec ? diagonal_t<Prec32>(c, ms, ls, diag, stream) : diagonal_t<Prec64>(c, ms, ls, diag, stream);
 }
 
 // ------------------------------------------------------------------------------------ BLAS-1 / halo
 
-__global__ void axpy_blocks_kernel(int64_t n, int nterms, const double *const *xs, const double *coef, double *y)
-{
-  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    double acc = y[i];
-    for (int t = 0; t < nterms; ++t) acc = fma(coef[t], xs[t][i], acc);
-    y[i] = acc;
-  }
-}
-
-struct AxpyArgs {
-  const double *x[MAX_BLOCKS];
-  double coef[MAX_BLOCKS];
+extern "C++" {
+template <typename T> struct AxpyArgs {
+  const T *x[MAX_BLOCKS];
+  T coef[MAX_BLOCKS];
   int n;
 };
-__global__ __launch_bounds__(256) void axpy_kernel(int64_t n, AxpyArgs a, double *y)
+template <typename T> __global__ __launch_bounds__(256) void axpy_kernel(int64_t n, AxpyArgs<T> a, T *y)
 {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-    double acc = y[i];
+    T acc = y[i];
     for (int t = 0; t < a.n; ++t) acc = fma(a.coef[t], a.x[t][i], acc);
     y[i] = acc;
   }
 }
+
+template <typename T>
+static int tensorproduct_add_t(stfem_ctx *c, int nrows, int ncols, const double *A, stfem_vec *cv, const stfem_vec *b,
+                               hipStream_t st)
+{
+  for (int i = 0; i < nrows; ++i)
+    for (int j0 = 0; j0 < ncols; j0 += MAX_BLOCKS) {
+      AxpyArgs<T> a;
+      a.n = 0;
+      for (int j = j0; j < std::min(ncols, j0 + MAX_BLOCKS); ++j)
+        if (A[size_t(i) * ncols + j] != 0.0) { // operators.h:246
+          if (cv->blk[i] == b->blk[j]) return STFEM_ERR_ALIAS;
+          a.x[a.n] = static_cast<const T *>(b->blk[j]);
+          a.coef[a.n++] = T(A[size_t(i) * ncols + j]);
+        }
+      if (a.n == 0) continue;
+      const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 256 * 16);
+      hipLaunchKernelGGL(axpy_kernel<T>, dim3(grid), dim3(256), 0, st, c->ndofs, a, static_cast<T *>(cv->blk[i]));
+    }
+  return STFEM_OK;
+}
+
+} // extern "C++"
 
 int stfem_tensorproduct_add(stfem_ctx *c, int nrows, int ncols, const double *A, stfem_vec *cv,
                             const stfem_vec *b, void *stream)
@@ -573,34 +679,26 @@ int stfem_tensorproduct_add(stfem_ctx *c, int nrows, int ncols, const double *A,
   if (cv->nb != nrows || b->nb != ncols) return STFEM_ERR_SHAPE_MISMATCH;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int i = 0; i < nrows; ++i)
-    for (int j0 = 0; j0 < ncols; j0 += MAX_BLOCKS) {
-      AxpyArgs a;
-      a.n = 0;
-      for (int j = j0; j < std::min(ncols, j0 + MAX_BLOCKS); ++j)
-        if (A[size_t(i) * ncols + j] != 0.0) { // operators.h:246
-          if (cv->blk[i] == b->blk[j]) return STFEM_ERR_ALIAS;
-          a.x[a.n] = b->blk[j];
-          a.coef[a.n++] = A[size_t(i) * ncols + j];
-        }
-      if (a.n == 0) continue;
-      const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 256 * 16);
-      hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, st, c->ndofs, a, cv->blk[i]);
-    }
-  return STFEM_OK;
+  return c->prec ? tensorproduct_add_t<float>(c, nrows, ncols, A, cv, b, st)
+                 : tensorproduct_add_t<double>(c, nrows, ncols, A, cv, b, st);
 }
 
-__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const double *a, const double *b, double *out)
+extern "C++" {
+// local dot product, accumulated in double for both precisions
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T *a, const T *b, double *out)
 {
   __shared__ double red[4];
   double s = 0.0;
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    s = fma(a[i], b[i], s);
+    s = fma(double(a[i]), double(b[i]), s);
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
+
+} // extern "C++"
 
 int stfem_dot(stfem_ctx *c, const stfem_vec *a, const stfem_vec *b, int64_t n_own, double *out, void *stream)
 {
@@ -610,18 +708,28 @@ int stfem_dot(stfem_ctx *c, const stfem_vec *a, const stfem_vec *b, int64_t n_ow
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(double), st));
   const unsigned grid = (unsigned)std::min<int64_t>((n_own + 255) / 256, 1024);
-  for (int blk = 0; blk < a->nb; ++blk)
-    hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(256), 0, st, n_own, a->blk[blk], b->blk[blk], c->d_scratch);
+  for (int blk = 0; blk < a->nb; ++blk) {
+    if (c->prec)
+      hipLaunchKernelGGL(dot_kernel<float>, dim3(grid), dim3(256), 0, st, n_own, static_cast<const float *>(a->blk[blk]),
+                         static_cast<const float *>(b->blk[blk]), c->d_scratch);
+    else
+      hipLaunchKernelGGL(dot_kernel<double>, dim3(grid), dim3(256), 0, st, n_own, static_cast<const double *>(a->blk[blk]),
+                         static_cast<const double *>(b->blk[blk]), c->d_scratch);
+  }
   HIP_TRY(hipMemcpyAsync(out, c->d_scratch, sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return STFEM_OK;
 }
 
-__global__ __launch_bounds__(256) void plane_copy_kernel(int64_t n, const double *src, double *dst, int add)
+extern "C++" {
+template <typename T>
+__global__ __launch_bounds__(256) void plane_copy_kernel(int64_t n, const T *src, T *dst, int add)
 {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
     dst[i] = add ? dst[i] + src[i] : src[i];
 }
+
+} // extern "C++"
 
 int stfem_plane_pack(stfem_ctx *c, const stfem_vec *v, int iz, void *buf, void *stream)
 {
@@ -629,8 +737,9 @@ int stfem_plane_pack(stfem_ctx *c, const stfem_vec *v, int iz, void *buf, void *
   HIP_TRY(hipSetDevice(c->device));
   const int64_t plane = int64_t(c->nd[0]) * c->nd[1];
   for (int b = 0; b < v->nb; ++b)
-    HIP_TRY(hipMemcpyAsync(static_cast<double *>(buf) + b * plane, v->blk[b] + plane * iz,
-                           plane * sizeof(double), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(buf) + size_t(b) * plane * c->es,
+                           static_cast<const char *>(v->blk[b]) + size_t(plane) * iz * c->es, plane * c->es,
+                           hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
   return STFEM_OK;
 }
 
@@ -640,9 +749,15 @@ int stfem_plane_unpack(stfem_ctx *c, stfem_vec *v, int iz, const void *buf, int 
   HIP_TRY(hipSetDevice(c->device));
   const int64_t plane = int64_t(c->nd[0]) * c->nd[1];
   const unsigned grid = (unsigned)std::min<int64_t>((plane + 255) / 256, 4096);
-  for (int b = 0; b < v->nb; ++b)
-    hipLaunchKernelGGL(plane_copy_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), plane,
-                       static_cast<const double *>(buf) + b * plane, v->blk[b] + plane * iz, add);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int b = 0; b < v->nb; ++b) {
+    if (c->prec)
+      hipLaunchKernelGGL(plane_copy_kernel<float>, dim3(grid), dim3(256), 0, st, plane,
+                         static_cast<const float *>(buf) + b * plane, static_cast<float *>(v->blk[b]) + plane * iz, add);
+    else
+      hipLaunchKernelGGL(plane_copy_kernel<double>, dim3(grid), dim3(256), 0, st, plane,
+                         static_cast<const double *>(buf) + b * plane, static_cast<double *>(v->blk[b]) + plane * iz, add);
+  }
   return STFEM_OK;
 }
 

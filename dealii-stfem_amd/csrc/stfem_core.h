@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 namespace stfem {
+namespace STFEM_PREC {
 
 template <int P, int NBM> struct Geometry {
   static constexpr int N = P + 1;
@@ -32,14 +33,14 @@ template <int P, int NBM> struct Geometry {
 //     on exit the nodal result plane of (cell, output block blk, z-plane k).
 template <int P, int NBM>
 __device__ __forceinline__ void
-cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, int blk, int k,
-          bool in_active, bool out_active, const double (&aK)[NBM], const double (&aM)[NBM],
-          double (&PA)[(P + 1) * (P + 1)])
+cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, int blk, int k,
+          bool in_active, bool out_active, const real_t (&aK)[NBM], const real_t (&aM)[NBM],
+          real_t (&PA)[(P + 1) * (P + 1)])
 {
   using G = Geometry<P, NBM>;
   constexpr int N = G::N;
   constexpr int CBS = G::CBS;
-  double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+  real_t *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
 #ifdef STFEM_ABLATION
   const bool no_lds = prm.experiment & 256;
 #else
@@ -62,25 +63,25 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
   // Row by row (fixed y, line along z): combine the input blocks, interpolate both combinations
   // and apply the z Laplacian while only one line is in flight, so that the peak register need
   // stays at the two result planes plus one line.
-  double Ua[N * N], R[N * N];
+  real_t Ua[N * N], R[N * N];
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
-    double ua[N], ub[N];
+    real_t ua[N], ub[N];
     STFEM_UNROLL
-    for (int z = 0; z < N; ++z) ua[z] = ub[z] = 0.0;
+    for (int z = 0; z < N; ++z) ua[z] = ub[z] = real_t(0);
     STFEM_UNROLL
     for (int i = 0; i < NBM; ++i) {
       if (i < prm.nbi) {
-        const double *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
+        const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
         STFEM_UNROLL
         for (int z = 0; z < N; ++z) {
-          const double v = no_lds ? 1.0 + z : in_lds[z * N * N + y * N + k];
+          const real_t v = no_lds ? real_t(1) + z : in_lds[z * N * N + y * N + k];
           ua[z] = fma(aK[i], v, ua[z]);
           ub[z] = fma(aM[i], v, ub[z]);
         }
       }
     }
-    double ta[N], tb[N], tl[N];
+    real_t ta[N], tb[N], tl[N];
     eo_apply<N, +1>(prm.eo_Si, ua, ta);
     eo_apply<N, +1>(prm.eo_Si, ub, tb);
     // Cartesian cell, coefficient constant in the cell: D^T c D collapses to c * L (one sweep)
@@ -152,14 +153,14 @@ cell_core(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, in
 // layout A, the flux contraction needs all three gradient components at one point (layout B).
 template <int P, int NBM>
 __device__ __forceinline__ void
-cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_wave, int blk, int k,
-                  bool in_active, bool out_active, const double (&aK)[NBM], const double (&aM)[NBM],
-                  const double *__restrict__ met, double (&PA)[(P + 1) * (P + 1)])
+cell_core_general(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, int blk, int k,
+                  bool in_active, bool out_active, const real_t (&aK)[NBM], const real_t (&aM)[NBM],
+                  const real_t *__restrict__ met, real_t (&PA)[(P + 1) * (P + 1)])
 {
   using G = Geometry<P, NBM>;
   constexpr int N = G::N;
   constexpr int CBS = G::CBS;
-  double *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+  real_t *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
 
   // ---- A: interpolate x, y
   plane_sweep<N, +1, true>(prm.eo_S, PA);
@@ -174,25 +175,25 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
 
   // ---- B1: temporal combination + interpolate z: Ua (Laplace part), R (mass part) at the
   // quadrature points of this lane's x-plane
-  double Ua[N * N], R[N * N];
+  real_t Ua[N * N], R[N * N];
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
-    double ua[N], ub[N];
+    real_t ua[N], ub[N];
     STFEM_UNROLL
-    for (int z = 0; z < N; ++z) ua[z] = ub[z] = 0.0;
+    for (int z = 0; z < N; ++z) ua[z] = ub[z] = real_t(0);
     STFEM_UNROLL
     for (int i = 0; i < NBM; ++i) {
       if (i < prm.nbi) {
-        const double *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
+        const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
         STFEM_UNROLL
         for (int z = 0; z < N; ++z) {
-          const double v = in_lds[z * N * N + y * N + k];
+          const real_t v = in_lds[z * N * N + y * N + k];
           ua[z] = fma(aK[i], v, ua[z]);
           ub[z] = fma(aM[i], v, ub[z]);
         }
       }
     }
-    double ta[N], tb[N];
+    real_t ta[N], tb[N];
     eo_apply<N, +1>(prm.eo_S, ua, ta);
     eo_apply<N, +1>(prm.eo_S, ub, tb);
     STFEM_UNROLL
@@ -226,10 +227,10 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
   wave_lds_fence();
 
   // ---- B3: y derivative (whole plane), then point by point: z derivative, metric, fluxes
-  double Gy[N * N];
+  real_t Gy[N * N];
   STFEM_UNROLL
   for (int z = 0; z < N; ++z) {
-    double x[N], y[N];
+    real_t x[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = Ua[i * N + z];
     eo_apply<N, -1>(prm.eo_Dq, x, y);
@@ -238,7 +239,7 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
   }
   // metric terms are streamed one row (fixed y, all z) ahead; the empty asm statements keep the
   // compiler from hoisting every row's loads to the top (350 VGPRs of loads in flight)
-  double mrow[2][N][8];
+  real_t mrow[2][N][8];
   STFEM_UNROLL
   for (int z = 0; z < N; ++z)
     STFEM_UNROLL
@@ -246,24 +247,24 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
     if (y + 1 < N) {
-      const double *mp = met; // laundered: loads through it cannot be hoisted above this point
+      const real_t *mp = met; // laundered: loads through it cannot be hoisted above this point
       asm volatile("" : "+v"(mp));
       STFEM_UNROLL
       for (int z = 0; z < N; ++z)
         STFEM_UNROLL
       for (int c = 0; c < 8; ++c) mrow[(y + 1) & 1][z][c] = mp[(z * N * N + (y + 1) * N + k) * 8 + c];
     }
-    double ur[N], gzr[N], fz[N], t[N];
+    real_t ur[N], gzr[N], fz[N], t[N];
     STFEM_UNROLL
     for (int z = 0; z < N; ++z) ur[z] = Ua[y * N + z];
     eo_apply<N, -1>(prm.eo_Dq, ur, gzr);
     STFEM_UNROLL
     for (int z = 0; z < N; ++z) {
       const int q = z * N * N + y * N + k;
-      const double gx = cb_lds[q], gy = Gy[y * N + z], gz = gzr[z];
-      const double *m = mrow[y & 1][z];
-      const double fx = fma(m[0], gx, fma(m[1], gy, m[2] * gz));
-      const double fy = fma(m[1], gx, fma(m[3], gy, m[4] * gz));
+      const real_t gx = cb_lds[q], gy = Gy[y * N + z], gz = gzr[z];
+      const real_t *m = mrow[y & 1][z];
+      const real_t fx = fma(m[0], gx, fma(m[1], gy, m[2] * gz));
+      const real_t fy = fma(m[1], gx, fma(m[3], gy, m[4] * gz));
       fz[z] = fma(m[2], gx, fma(m[4], gy, m[5] * gz));
       R[y * N + z] *= m[6];
       Gy[y * N + z] = fy;
@@ -276,7 +277,7 @@ cell_core_general(const SweepParams &prm, double *__restrict__ lds, int cell_in_
   }
   STFEM_UNROLL
   for (int z = 0; z < N; ++z) { // R += Dy^T Fy
-    double x[N], y[N];
+    real_t x[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = Gy[i * N + z];
     eo_apply<N, -1>(prm.eo_DqT, x, y);
@@ -348,4 +349,5 @@ template <int P> __device__ __forceinline__ bool constrained(const PlaneMask &m,
 
 constexpr int round_nbm(int nbm) { return nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8); }
 
+} // namespace STFEM_PREC
 } // namespace stfem

@@ -12,9 +12,12 @@
 // 1D matrices are applied in even-odd form (Kopriva / Kronbichler-Kormann): 21 instead of 25
 // multiply-adds for N = 5, and only eo_size(N) distinct constants, which live in SGPRs.
 #pragma once
+#include "stfem_kernels.h"
+
 #include <hip/hip_runtime.h>
 
 namespace stfem {
+namespace STFEM_PREC {
 
 #define STFEM_UNROLL _Pragma("unroll")
 
@@ -26,12 +29,12 @@ __host__ __device__ constexpr int eo_size_c(int n)
 // y = X x for an N x N matrix with X[q][a] = SIGN * X[N-1-q][N-1-a], constants packed by
 // host_tables.cpp::eo_pack.  `c` must be wave-uniform (kernel argument -> SGPRs).
 template <int N, int SIGN>
-__device__ __forceinline__ void eo_apply(const double *__restrict__ c, const double (&x)[N],
-                                         double (&y)[N])
+__device__ __forceinline__ void eo_apply(const real_t *__restrict__ c, const real_t (&x)[N],
+                                         real_t (&y)[N])
 {
   constexpr int H = N / 2;
   constexpr bool ODD = (N & 1) != 0;
-  double xe[H > 0 ? H : 1], xo[H > 0 ? H : 1];
+  real_t xe[H > 0 ? H : 1], xo[H > 0 ? H : 1];
   STFEM_UNROLL
   for (int i = 0; i < H; ++i) {
     xe[i] = x[i] + x[N - 1 - i];
@@ -39,8 +42,8 @@ __device__ __forceinline__ void eo_apply(const double *__restrict__ c, const dou
   }
   STFEM_UNROLL
   for (int q = 0; q < H; ++q) {
-    double a = c[q * H] * xe[0];
-    double b = c[H * H + q * H] * xo[0];
+    real_t a = c[q * H] * xe[0];
+    real_t b = c[H * H + q * H] * xo[0];
     STFEM_UNROLL
     for (int i = 1; i < H; ++i) {
       a = fma(c[q * H + i], xe[i], a);
@@ -51,7 +54,7 @@ __device__ __forceinline__ void eo_apply(const double *__restrict__ c, const dou
     y[N - 1 - q] = SIGN > 0 ? a - b : b - a;
   }
   if (ODD) {
-    double m;
+    real_t m;
     if (SIGN > 0) {
       m = c[2 * H * H + 2 * H] * x[H];
       STFEM_UNROLL
@@ -68,12 +71,12 @@ __device__ __forceinline__ void eo_apply(const double *__restrict__ c, const dou
 // y = X^T x for a symmetric-type X packed in c (the transpose has the same constants:
 // ee^T[q][i] = ee[i][q], oo^T[q][i] = oo[i][q], em <-> mm), so S and S^T share their SGPRs.
 template <int N>
-__device__ __forceinline__ void eo_apply_T(const double *__restrict__ c, const double (&x)[N],
-                                           double (&y)[N])
+__device__ __forceinline__ void eo_apply_T(const real_t *__restrict__ c, const real_t (&x)[N],
+                                           real_t (&y)[N])
 {
   constexpr int H = N / 2;
   constexpr bool ODD = (N & 1) != 0;
-  double xe[H > 0 ? H : 1], xo[H > 0 ? H : 1];
+  real_t xe[H > 0 ? H : 1], xo[H > 0 ? H : 1];
   STFEM_UNROLL
   for (int i = 0; i < H; ++i) {
     xe[i] = x[i] + x[N - 1 - i];
@@ -81,8 +84,8 @@ __device__ __forceinline__ void eo_apply_T(const double *__restrict__ c, const d
   }
   STFEM_UNROLL
   for (int q = 0; q < H; ++q) {
-    double a = c[q] * xe[0];
-    double b = c[H * H + q] * xo[0];
+    real_t a = c[q] * xe[0];
+    real_t b = c[H * H + q] * xo[0];
     STFEM_UNROLL
     for (int i = 1; i < H; ++i) {
       a = fma(c[i * H + q], xe[i], a);
@@ -93,7 +96,7 @@ __device__ __forceinline__ void eo_apply_T(const double *__restrict__ c, const d
     y[N - 1 - q] = a - b;
   }
   if (ODD) {
-    double m = c[2 * H * H + 2 * H] * x[H];
+    real_t m = c[2 * H * H + 2 * H] * x[H];
     STFEM_UNROLL
     for (int i = 0; i < H; ++i) m = fma(c[2 * H * H + i], xe[i], m); // mm^T = em
     y[H] = m;
@@ -102,11 +105,11 @@ __device__ __forceinline__ void eo_apply_T(const double *__restrict__ c, const d
 
 // In-place sweep with the transposed matrix
 template <int N, bool ALONG_FAST>
-__device__ __forceinline__ void plane_sweep_T(const double *__restrict__ c, double (&P)[N * N])
+__device__ __forceinline__ void plane_sweep_T(const real_t *__restrict__ c, real_t (&P)[N * N])
 {
   STFEM_UNROLL
   for (int o = 0; o < N; ++o) {
-    double x[N], y[N];
+    real_t x[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
     eo_apply_T<N>(c, x, y);
@@ -118,11 +121,11 @@ __device__ __forceinline__ void plane_sweep_T(const double *__restrict__ c, doub
 // In-place sweep over an N x N register plane P[s*N + f] (s slow, f fast index).
 // ALONG_FAST: contract the fast index for every slow index; else contract the slow index.
 template <int N, int SIGN, bool ALONG_FAST>
-__device__ __forceinline__ void plane_sweep(const double *__restrict__ c, double (&P)[N * N])
+__device__ __forceinline__ void plane_sweep(const real_t *__restrict__ c, real_t (&P)[N * N])
 {
   STFEM_UNROLL
   for (int o = 0; o < N; ++o) {
-    double x[N], y[N];
+    real_t x[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
     eo_apply<N, SIGN>(c, x, y);
@@ -134,20 +137,20 @@ __device__ __forceinline__ void plane_sweep(const double *__restrict__ c, double
 // R += s * D^T ( D U ) along one in-register direction (collocation Laplacian of that
 // direction with the quadrature weights folded into D).  D antisymmetric-type, as is D^T.
 template <int N, bool ALONG_FAST>
-__device__ __forceinline__ void plane_laplace_acc(const double *__restrict__ cD,
-                                                  const double *__restrict__ cDT, double s,
-                                                  const double (&U)[N * N], double (&R)[N * N])
+__device__ __forceinline__ void plane_laplace_acc(const real_t *__restrict__ cD,
+                                                  const real_t *__restrict__ cDT, real_t s,
+                                                  const real_t (&U)[N * N], real_t (&R)[N * N])
 {
   STFEM_UNROLL
   for (int o = 0; o < N; ++o) {
-    double x[N], t[N], y[N];
+    real_t x[N], t[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? U[o * N + i] : U[i * N + o];
     eo_apply<N, -1>(cD, x, t);
     eo_apply<N, -1>(cDT, t, y);
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) {
-      double &r = ALONG_FAST ? R[o * N + i] : R[i * N + o];
+      real_t &r = ALONG_FAST ? R[o * N + i] : R[i * N + o];
       r = fma(s, y[i], r);
     }
   }
@@ -156,13 +159,13 @@ __device__ __forceinline__ void plane_laplace_acc(const double *__restrict__ cD,
 // Same, overwriting U in place with s * D^T D U (used for the direction that needs its own
 // layout, whose result is then transposed and added).
 template <int N, bool ALONG_FAST>
-__device__ __forceinline__ void plane_laplace_inplace(const double *__restrict__ cD,
-                                                      const double *__restrict__ cDT, double s,
-                                                      double (&U)[N * N])
+__device__ __forceinline__ void plane_laplace_inplace(const real_t *__restrict__ cD,
+                                                      const real_t *__restrict__ cDT, real_t s,
+                                                      real_t (&U)[N * N])
 {
   STFEM_UNROLL
   for (int o = 0; o < N; ++o) {
-    double x[N], t[N], y[N];
+    real_t x[N], t[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? U[o * N + i] : U[i * N + o];
     eo_apply<N, -1>(cD, x, t);
@@ -174,18 +177,18 @@ __device__ __forceinline__ void plane_laplace_inplace(const double *__restrict__
 
 // R += s * (X U) along one in-register direction (X of symmetric type)
 template <int N, bool ALONG_FAST>
-__device__ __forceinline__ void plane_sweep_acc(const double *__restrict__ c, double s,
-                                                const double (&U)[N * N], double (&R)[N * N])
+__device__ __forceinline__ void plane_sweep_acc(const real_t *__restrict__ c, real_t s,
+                                                const real_t (&U)[N * N], real_t (&R)[N * N])
 {
   STFEM_UNROLL
   for (int o = 0; o < N; ++o) {
-    double x[N], y[N];
+    real_t x[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? U[o * N + i] : U[i * N + o];
     eo_apply<N, +1>(c, x, y);
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) {
-      double &r = ALONG_FAST ? R[o * N + i] : R[i * N + o];
+      real_t &r = ALONG_FAST ? R[o * N + i] : R[i * N + o];
       r = fma(s, y[i], r);
     }
   }
@@ -193,12 +196,12 @@ __device__ __forceinline__ void plane_sweep_acc(const double *__restrict__ c, do
 
 // P <- s * (X P) in place
 template <int N, bool ALONG_FAST>
-__device__ __forceinline__ void plane_sweep_scaled(const double *__restrict__ c, double s,
-                                                   double (&P)[N * N])
+__device__ __forceinline__ void plane_sweep_scaled(const real_t *__restrict__ c, real_t s,
+                                                   real_t (&P)[N * N])
 {
   STFEM_UNROLL
   for (int o = 0; o < N; ++o) {
-    double x[N], y[N];
+    real_t x[N], y[N];
     STFEM_UNROLL
     for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
     eo_apply<N, +1>(c, x, y);
@@ -222,10 +225,11 @@ __device__ __forceinline__ void wave_lds_fence()
 // Pins a register plane at this program point: everything that produces it is scheduled before,
 // everything that consumes it after.  (The DAG scheduler otherwise sinks whole sweeps next to
 // their far-away use and keeps three extra planes alive.)  Emits no instruction.
-template <int M> __device__ __forceinline__ void pin(double (&P)[M])
+template <int M> __device__ __forceinline__ void pin(real_t (&P)[M])
 {
   STFEM_UNROLL
   for (int e = 0; e < M; ++e) asm volatile("" : "+v"(P[e]));
 }
 
+} // namespace STFEM_PREC
 } // namespace stfem

@@ -1,83 +1,29 @@
-// Kernel parameter block and launch entry points shared by stfem_kernels.hip and stfem_capi.hip.
+// Kernel parameter blocks and launch entry points shared by the device translation units and
+// stfem_capi.hip.  Everything precision-dependent lives in stfem_kernels_decl.h, instantiated
+// for fp64 (namespace stfem::f64, the solver precision) and fp32 (stfem::f32, the precision of
+// the reference's multigrid levels, tests/tp_01.cc:780,801-806).
 #pragma once
 #include <cstdint>
 
 namespace stfem {
-
 constexpr int MAX_BLOCKS = 8; // temporal blocks handled by one launch (larger systems are tiled)
 constexpr int EO_N = 16;      // >= eo_size(5)
-
-struct SweepParams {
-  const double *src[MAX_BLOCKS];
-  double *dst[MAX_BLOCKS];
-  double alpha[MAX_BLOCKS * MAX_BLOCKS]; // [j*nbi + i], already transposed for Tvmult
-  double beta[MAX_BLOCKS * MAX_BLOCKS];
-  int nbi, nbo;         // input (source) and output (destination) temporal blocks
-  int ncx, ncy, ncz;    // cells per direction
-  int nx, ny, nz;       // DoFs per direction
-  int64_t ncells;
-  int dmask;            // Dirichlet faces
-  double vol;           // hx*hy*hz
-  double ihx2, ihy2, ihz2;
-  const double *coef_lap;  // per cell or nullptr
-  const double *coef_mass; // per cell or nullptr
-  int experiment;          // ablation bits for cell_core (256: no LDS traffic in the core); results wrong if set
-  double eo_Si[EO_N], eo_L[EO_N]; // even-odd packed: interpolation (weights folded), 1D Laplacian
-  // general-geometry path: plain interpolation S, collocation derivative D and D^T, and the
-  // per-quadrature-point metric records [cell][qz][qy][qx][8] = (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad)
-  double eo_S[EO_N], eo_Dq[EO_N], eo_DqT[EO_N];
-  const double *metric;
-};
-
-// Decomposition used by the "tile" variant: a workgroup owns a tile of cw x rows cells in x-y and
-// marches through lz cell layers in z, accumulating shared DoFs in LDS.  x-neighbouring tiles
-// are launched in two colours (odd tiles read-modify-write the shared columns); partial sums on
-// a tile's upper y/z faces go to per-tile halo slabs and are added to their owner by a small
-// fix-up kernel.  No global atomics and no zeroing of dst are needed.
-struct TilePlan {
-  int cw, rows;      // cells per wave along x, waves (= cell rows along y) per tile
-  int ntx, nty, ntc; // tiles in x, y and chunks in z
-  int lz;            // cell layers per chunk (the last chunk may have fewer)
-  int tX, tY, zp;    // slab extents: P*cw+1, P*rows+1, P*lz+1
-  double *yh, *zh;   // halo slabs: yh[tile][block][zl][X], zh[tile][block][Y][X]
-  double *xl, *xr;   // x-face slabs of odd tiles: [tile][block][zl][Y] (their X = 0 / X = xext columns)
-  int add;           // accumulate into dst instead of overwriting
-  int xcolor;        // parity of the tile x-index handled by this launch
-  int stagger;       // start delay (units of 1024 cycles) of every other group of stagger_div blocks
-  int stagger_div;
-  int experiment;    // ablation bit mask (STFEM_EXP; results are wrong when nonzero): 1 no src loads,
-                     // 2 no cell core, 4 no LDS accumulation, 8 no store phase
-};
-
-// Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.
-// Variant "atomic": result scattered with global fp64 atomics into a pre-zeroed dst.
-// Returns 0, or -2 if (p, nbm) has no instantiation.
-int launch_cart_atomic(int p, const SweepParams &prm, void *stream);
-const char *cart_atomic_name(int p, int nbm);
-
-// Forward diagonal of ms*M_c + ls*K_c (reference operators.h:1092-1110), accumulated with fp64
-// atomics into a zeroed vector.  Cartesian cells use the 1D diagonals m1[a] = (S^T W S)_aa and
-// l1[a] = (S^T D^T W D S)_aa; general cells sum over the quadrature points with the metric.
-struct DiagParams {
-  double *diag;
-  int ncx, ncy, ncz, nx, ny, p, dmask;
-  double ms, ls;          // effective scalings (1 where a coefficient replaces them)
-  double vol, ihx2, ihy2, ihz2;
-  const double *coef_lap, *coef_mass; // per cell or nullptr (Cartesian path)
-  const double *metric;               // general path, coefficients baked in
-  double m1[8], l1[8];                // 1D diagonals (Cartesian)
-  double S[64], D[64];                // plain S[q][a], D[q][a] (general)
-};
-int launch_diagonal(const DiagParams &prm, void *stream);
-
-// Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm); returns 0 or -2.
-int tile_geometry(int p, int nbm, TilePlan &plan);
-int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);
-// fills metric[cell][q][8] from the vertex grid (device pointers); coef_* may be null,
-// layout 1 = per cell, 2 = per (cell, q)
-int launch_build_metric(int p, const int nc[3], const double *d_vertices, const double *d_xq,
-                        const double *d_wq, const double *coef_lap, int lap_layout,
-                        const double *coef_mass, int mass_layout, double *d_metric, void *stream);
-const char *cart_tile_name(int p, int nbm);
-
 } // namespace stfem
+
+#define STFEM_REAL double
+#define STFEM_NS f64
+#include "stfem_kernels_decl.h"
+#undef STFEM_REAL
+#undef STFEM_NS
+#define STFEM_REAL float
+#define STFEM_NS f32
+#include "stfem_kernels_decl.h"
+#undef STFEM_REAL
+#undef STFEM_NS
+
+// the namespace a device translation unit implements (make passes -DSTFEM_F32 for the fp32 objects)
+#ifdef STFEM_F32
+#define STFEM_PREC f32
+#else
+#define STFEM_PREC f64
+#endif

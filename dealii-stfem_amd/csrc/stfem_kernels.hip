@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 namespace stfem {
+namespace STFEM_PREC {
 
 namespace {
 
@@ -17,11 +18,11 @@ __global__ __launch_bounds__(256) void st_sweep_cart_atomic(const SweepParams pr
 {
   using G = Geometry<P, NBM>;
   constexpr int N = G::N;
-  __shared__ double lds_all[G::WAVES * G::LDS_PER_WAVE];
+  __shared__ real_t lds_all[G::WAVES * G::LDS_PER_WAVE];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  double *lds = lds_all + wave * G::LDS_PER_WAVE;
+  real_t *lds = lds_all + wave * G::LDS_PER_WAVE;
 
   const bool lane_ok = lane < G::ACTIVE;
   const int l = lane_ok ? lane : 0;
@@ -39,35 +40,35 @@ __global__ __launch_bounds__(256) void st_sweep_cart_atomic(const SweepParams pr
   const bool out_active = cell_ok && blk < prm.nbo;
 
   // temporal coefficients of this lane's output block, with the cell factor folded in
-  const double fK = prm.vol * (prm.coef_lap ? prm.coef_lap[cc] : 1.0);
-  const double fM = prm.vol * (prm.coef_mass ? prm.coef_mass[cc] : 1.0);
-  double aK[NBM], aM[NBM];
+  const real_t fK = prm.vol * (prm.coef_lap ? prm.coef_lap[cc] : real_t(1));
+  const real_t fM = prm.vol * (prm.coef_mass ? prm.coef_mass[cc] : real_t(1));
+  real_t aK[NBM], aM[NBM];
   STFEM_UNROLL
   for (int i = 0; i < NBM; ++i) {
     const bool ok = blk < prm.nbo && i < prm.nbi;
-    aK[i] = ok ? prm.alpha[blk * prm.nbi + i] * fK : 0.0;
-    aM[i] = ok ? prm.beta[blk * prm.nbi + i] * fM : 0.0;
+    aK[i] = ok ? prm.alpha[blk * prm.nbi + i] * fK : real_t(0);
+    aM[i] = ok ? prm.beta[blk * prm.nbi + i] * fM : real_t(0);
   }
 
   const PlaneMask pm = plane_mask<P>(prm, cx, cy, cz, k);
   const int64_t base = int64_t(P) * cx + int64_t(prm.nx) * (int64_t(P) * cy + int64_t(prm.ny) * (int64_t(P) * cz + k));
 
-  double PA[N * N];
+  real_t PA[N * N];
   {
-    const double *s = prm.src[in_active ? blk : 0] + base;
+    const real_t *s = prm.src[in_active ? blk : 0] + base;
     STFEM_UNROLL
     for (int y = 0; y < N; ++y)
       STFEM_UNROLL
     for (int x = 0; x < N; ++x) {
-      const double v = in_active ? s[int64_t(y) * prm.nx + x] : 0.0;
-      PA[y * N + x] = constrained<P>(pm, y, x) ? 0.0 : v;
+      const real_t v = in_active ? s[int64_t(y) * prm.nx + x] : real_t(0);
+      PA[y * N + x] = constrained<P>(pm, y, x) ? real_t(0) : v;
     }
   }
 
   cell_core<P, NBM>(prm, lds, cell_in_wave, blk, k, in_active, out_active, aK, aM, PA);
 
   if (out_active) {
-    double *d = prm.dst[blk] + base;
+    real_t *d = prm.dst[blk] + base;
     STFEM_UNROLL
     for (int y = 0; y < N; ++y)
       STFEM_UNROLL
@@ -109,24 +110,24 @@ __global__ __launch_bounds__(128) void diagonal_kernel(const DiagParams prm)
                      ((prm.dmask & 4) && iy == 0) || ((prm.dmask & 8) && iy == prm.ny - 1) ||
                      ((prm.dmask & 16) && iz == 0) || ((prm.dmask & 32) && iz == prm.p * prm.ncz);
     if (con) continue;
-    double v = 0.0;
+    real_t v = real_t(0);
     if (prm.metric) {
-      const double *m = prm.metric + cell * 8 * n3; // [q][8] records
+      const real_t *m = prm.metric + cell * 8 * n3; // [q][8] records
       for (int qz = 0; qz < n; ++qz)
         for (int qy = 0; qy < n; ++qy)
           for (int qx = 0; qx < n; ++qx) {
             const int q = qx + n * (qy + n * qz);
-            const double sa = prm.S[qx * n + a], sb = prm.S[qy * n + b], sc = prm.S[qz * n + c];
-            const double val = sa * sb * sc;
-            const double g0 = prm.D[qx * n + a] * sb * sc, g1 = sa * prm.D[qy * n + b] * sc, g2 = sa * sb * prm.D[qz * n + c];
-            const double *mq = m + q * 8;
+            const real_t sa = prm.S[qx * n + a], sb = prm.S[qy * n + b], sc = prm.S[qz * n + c];
+            const real_t val = sa * sb * sc;
+            const real_t g0 = prm.D[qx * n + a] * sb * sc, g1 = sa * prm.D[qy * n + b] * sc, g2 = sa * sb * prm.D[qz * n + c];
+            const real_t *mq = m + q * 8;
             v += prm.ms * mq[6] * val * val +
                  prm.ls * (mq[0] * g0 * g0 + mq[3] * g1 * g1 + mq[5] * g2 * g2 +
-                           2.0 * (mq[1] * g0 * g1 + mq[2] * g0 * g2 + mq[4] * g1 * g2));
+                           real_t(2) * (mq[1] * g0 * g1 + mq[2] * g0 * g2 + mq[4] * g1 * g2));
           }
     } else {
-      const double fK = prm.vol * (prm.coef_lap ? prm.coef_lap[cell] : 1.0);
-      const double fM = prm.vol * (prm.coef_mass ? prm.coef_mass[cell] : 1.0);
+      const real_t fK = prm.vol * (prm.coef_lap ? prm.coef_lap[cell] : real_t(1));
+      const real_t fM = prm.vol * (prm.coef_mass ? prm.coef_mass[cell] : real_t(1));
       v = prm.ms * fM * prm.m1[a] * prm.m1[b] * prm.m1[c] +
           prm.ls * fK * (prm.ihx2 * prm.l1[a] * prm.m1[b] * prm.m1[c] + prm.ihy2 * prm.m1[a] * prm.l1[b] * prm.m1[c] +
                          prm.ihz2 * prm.m1[a] * prm.m1[b] * prm.l1[c]);
@@ -164,4 +165,5 @@ int launch_cart_atomic(int p, const SweepParams &prm, void *stream)
 
 const char *cart_atomic_name(int, int) { return "st_sweep_cart_atomic"; }
 
+} // namespace STFEM_PREC
 } // namespace stfem

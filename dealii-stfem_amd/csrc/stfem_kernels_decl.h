@@ -1,0 +1,82 @@
+// Declarations of one precision instantiation (included by stfem_kernels.h once with
+// STFEM_REAL = double / STFEM_NS = f64 and once with float / f32; no include guard on purpose).
+namespace stfem {
+namespace STFEM_NS {
+
+using real_t = STFEM_REAL;
+
+struct SweepParams {
+  const real_t *src[MAX_BLOCKS];
+  real_t *dst[MAX_BLOCKS];
+  real_t alpha[MAX_BLOCKS * MAX_BLOCKS]; // [j*nbi + i], already transposed for Tvmult
+  real_t beta[MAX_BLOCKS * MAX_BLOCKS];
+  int nbi, nbo;         // input (source) and output (destination) temporal blocks
+  int ncx, ncy, ncz;    // cells per direction
+  int nx, ny, nz;       // DoFs per direction
+  int64_t ncells;
+  int dmask;            // Dirichlet faces
+  real_t vol;           // hx*hy*hz
+  real_t ihx2, ihy2, ihz2;
+  const real_t *coef_lap;  // per cell or nullptr
+  const real_t *coef_mass; // per cell or nullptr
+  int experiment;          // ablation bits for cell_core (256: no LDS traffic in the core); results wrong if set
+  real_t eo_Si[EO_N], eo_L[EO_N]; // even-odd packed: interpolation (weights folded), 1D Laplacian
+  // general-geometry path: plain interpolation S, collocation derivative D and D^T, and the
+  // per-quadrature-point metric records [cell][qz][qy][qx][8] = (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad)
+  real_t eo_S[EO_N], eo_Dq[EO_N], eo_DqT[EO_N];
+  const real_t *metric;
+};
+
+// Decomposition used by the "tile" variant: a workgroup owns a tile of cw x rows cells in x-y and
+// marches through lz cell layers in z, accumulating shared DoFs in LDS.  x-neighbouring tiles
+// are launched in two colours (odd tiles read-modify-write the shared columns); partial sums on
+// a tile's upper y/z faces go to per-tile halo slabs and are added to their owner by a small
+// fix-up kernel.  No global atomics and no zeroing of dst are needed.
+struct TilePlan {
+  int cw, rows;      // cells per wave along x, waves (= cell rows along y) per tile
+  int ntx, nty, ntc; // tiles in x, y and chunks in z
+  int lz;            // cell layers per chunk (the last chunk may have fewer)
+  int tX, tY, zp;    // slab extents: P*cw+1, P*rows+1, P*lz+1
+  real_t *yh, *zh;   // halo slabs: yh[tile][block][zl][X], zh[tile][block][Y][X]
+  real_t *xl, *xr;   // x-face slabs of odd tiles: [tile][block][zl][Y] (their X = 0 / X = xext columns)
+  int add;           // accumulate into dst instead of overwriting
+  int xcolor;        // parity of the tile x-index handled by this launch
+  int stagger;       // start delay (units of 1024 cycles) of every other group of stagger_div blocks
+  int stagger_div;
+  int experiment;    // ablation bit mask (STFEM_EXP; results are wrong when nonzero): 1 no src loads,
+                     // 2 no cell core, 4 no LDS accumulation, 8 no store phase
+};
+
+// Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.
+// Variant "atomic": result scattered with global fp64 atomics into a pre-zeroed dst.
+// Returns 0, or -2 if (p, nbm) has no instantiation.
+int launch_cart_atomic(int p, const SweepParams &prm, void *stream);
+const char *cart_atomic_name(int p, int nbm);
+
+// Forward diagonal of ms*M_c + ls*K_c (reference operators.h:1092-1110), accumulated with fp64
+// atomics into a zeroed vector.  Cartesian cells use the 1D diagonals m1[a] = (S^T W S)_aa and
+// l1[a] = (S^T D^T W D S)_aa; general cells sum over the quadrature points with the metric.
+struct DiagParams {
+  real_t *diag;
+  int ncx, ncy, ncz, nx, ny, p, dmask;
+  real_t ms, ls;          // effective scalings (1 where a coefficient replaces them)
+  real_t vol, ihx2, ihy2, ihz2;
+  const real_t *coef_lap, *coef_mass; // per cell or nullptr (Cartesian path)
+  const real_t *metric;               // general path, coefficients baked in
+  real_t m1[8], l1[8];                // 1D diagonals (Cartesian)
+  real_t S[64], D[64];                // plain S[q][a], D[q][a] (general)
+};
+int launch_diagonal(const DiagParams &prm, void *stream);
+
+// Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm); returns 0 or -2.
+int tile_geometry(int p, int nbm, TilePlan &plan);
+int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);
+// fills metric[cell][q][8] from the vertex grid (device pointers); coef_* may be null,
+// layout 1 = per cell, 2 = per (cell, q)
+int launch_build_metric(int p, const int nc[3], const double *d_vertices, const double *d_xq,
+                        const double *d_wq, const real_t *coef_lap, int lap_layout,
+                        const real_t *coef_mass, int mass_layout, real_t *d_metric, void *stream);
+const char *cart_tile_name(int p, int nbm);
+
+} // namespace STFEM_NS
+} // namespace stfem

@@ -32,6 +32,7 @@
 #endif
 
 namespace stfem {
+namespace STFEM_PREC {
 
 namespace {
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ int logical_block(int b, int nblocks)
 }
 
 template <int P>
-__device__ __forceinline__ void load_plane(const double *__restrict__ s, int nx, double (&PA)[(P + 1) * (P + 1)])
+__device__ __forceinline__ void load_plane(const real_t *__restrict__ s, int nx, real_t (&PA)[(P + 1) * (P + 1)])
 {
   constexpr int N = P + 1;
   STFEM_UNROLL
@@ -100,13 +101,17 @@ __device__ __forceinline__ void load_plane(const double *__restrict__ s, int nx,
 // vmcnt(0) at the next use.  The caller waits with wait_vmcnt(n), n <= number of VMEM
 // instructions this wave has issued since, before touching PA.
 template <int P>
-__device__ __forceinline__ void load_plane_async(const double *s, int nx, double (&PA)[(P + 1) * (P + 1)])
+__device__ __forceinline__ void load_plane_async(const real_t *s, int nx, real_t (&PA)[(P + 1) * (P + 1)])
 {
   constexpr int N = P + 1;
+#ifdef STFEM_F32
+  load_plane<P>(s, nx, PA); // fp32: ordinary (compiler-tracked) loads
+  return;
+#else
   typedef double d2 __attribute__((ext_vector_type(2)));
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
-    const double *row = s + int64_t(y) * nx;
+    const real_t *row = s + int64_t(y) * nx;
     STFEM_UNROLL
     for (int x = 0; x + 1 < N; x += 2) {
       d2 v;
@@ -115,11 +120,12 @@ __device__ __forceinline__ void load_plane_async(const double *s, int nx, double
       PA[y * N + x + 1] = v.y;
     }
     if (N & 1) {
-      double v;
+      real_t v;
       asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(v) : "v"(row), "n"((N - 1) * 8) : "memory");
       PA[y * N + N - 1] = v;
     }
   }
+#endif
 }
 
 template <int CNT> __device__ __forceinline__ void wait_vmcnt_imm()
@@ -147,13 +153,13 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   using G = Geometry<P, NBM>;
   constexpr int N = TG::N;
   constexpr int TX = TG::TX, TY = TG::TY, PLANE = TG::PLANE;
-  __shared__ double smem[TG::LDS_DOUBLES];
-  double *acc = smem; // [blk][k][Y][X], aliases the transpose slabs
+  __shared__ real_t smem[TG::LDS_DOUBLES];
+  real_t *acc = smem; // [blk][k][Y][X], aliases the transpose slabs
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  double *lds = smem + wave * G::LDS_PER_WAVE;
+  real_t *lds = smem + wave * G::LDS_PER_WAVE;
 
   // tiles of this launch's x colour
   const int ntxh = (tp.ntx - COLOR + 1) / 2; // tiles of this launch's x colour
@@ -176,12 +182,12 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   const int64_t cell_xy = cx + int64_t(prm.ncx) * cy;
   const int64_t cells_per_layer = int64_t(prm.ncx) * prm.ncy;
 
-  double aK0[NBM], aM0[NBM];
+  real_t aK0[NBM], aM0[NBM];
   STFEM_UNROLL
   for (int i = 0; i < NBM; ++i) {
     const bool ok = blk < prm.nbo && i < prm.nbi;
-    aK0[i] = ok ? prm.alpha[blk * prm.nbi + i] * prm.vol : 0.0;
-    aM0[i] = ok ? prm.beta[blk * prm.nbi + i] * prm.vol : 0.0;
+    aK0[i] = ok ? prm.alpha[blk * prm.nbi + i] * prm.vol : real_t(0);
+    aM0[i] = ok ? prm.beta[blk * prm.nbi + i] * prm.vol : real_t(0);
   }
 
   // which entries of this lane's result plane it initialises in the LDS slab ("owner")
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
   const int64_t xy_base = int64_t(P) * cx + int64_t(prm.nx) * (int64_t(P) * cy);
   // lanes that feed nothing still load from a valid address; their planes are never used
-  const double *src_lane = prm.src[in_active ? blk : 0] + xy_base + plane_stride * k;
-  double *a = acc + ((blk * N + k) * TY + P * cyl) * TX + P * cxl;
+  const real_t *src_lane = prm.src[in_active ? blk : 0] + xy_base + plane_stride * k;
+  real_t *a = acc + ((blk * N + k) * TY + P * cyl) * TX + P * cxl;
 
   const int xext = P * t.ncx, yext = P * t.ncy;
   const int ymax = t.last_y ? yext + 1 : yext; // rows [0, ymax) go to dst, row yext to yh otherwise
@@ -211,13 +217,15 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   // top plane of the previous layer: element tid + 256*m of [blk][Y][X] lives in this thread
-  double carry[TG::CARRY_REGS];
+  real_t carry[TG::CARRY_REGS];
   STFEM_UNROLL
-  for (int m = 0; m < TG::CARRY_REGS; ++m) carry[m] = 0.0;
+  for (int m = 0; m < TG::CARRY_REGS; ++m) carry[m] = real_t(0);
 
-  double PA[N * N];
+  real_t PA[N * N];
   load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
+#ifndef STFEM_F32
   wait_vmcnt_imm<0>();
+#endif
 #ifdef STFEM_ABLATION
 #define STFEM_LAYER_BARRIER() do { if (!(ex & 2048)) __syncthreads(); } while (0)
   const int ex = tp.experiment; // timing experiments only (tools/ablate.sh); results are wrong
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       for (int i = 0; i < tp.stagger; ++i) __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles each
   }
 
-  double dummy = 0.0;
+  real_t dummy = real_t(0);
   for (int layer = 0; layer < t.nlay; ++layer) {
     const int cz = t.cz0 + layer;
     const bool last_layer = layer == t.nlay - 1;
@@ -246,13 +254,13 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
       for (int x = 0; x < N; ++x)
-        if (constrained<P>(pm, y, x)) PA[y * N + x] = 0.0;
+        if (constrained<P>(pm, y, x)) PA[y * N + x] = real_t(0);
     }
-    double aK[NBM], aM[NBM];
+    real_t aK[NBM], aM[NBM];
     if (COEF) { // per-cell coefficients (operators.h:1060-1087) folded into the temporal weights
       const int64_t c = cell_xy + cells_per_layer * cz;
-      const double fK = prm.coef_lap ? prm.coef_lap[c] : 1.0;
-      const double fM = prm.coef_mass ? prm.coef_mass[c] : 1.0;
+      const real_t fK = prm.coef_lap ? prm.coef_lap[c] : real_t(1);
+      const real_t fM = prm.coef_mass ? prm.coef_mass[c] : real_t(1);
       STFEM_UNROLL
       for (int i = 0; i < NBM; ++i) {
         aK[i] = aK0[i] * fK;
@@ -268,9 +276,9 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
 
     // even tiles: fetch the odd neighbours' partial sums of the shared columns for this layer
     // (issued before the compute, consumed after it)
-    double xe[XE];
+    real_t xe[XE];
     STFEM_UNROLL
-    for (int m = 0; m < XE; ++m) xe[m] = 0.0;
+    for (int m = 0; m < XE; ++m) xe[m] = real_t(0);
     // slab entry m of this thread: (side, row) -> LDS slab index or -1; evaluated twice (here for
     // the load, after the core for the add) rather than kept in registers across the core
     auto xe_slot = [&](int m, int &side, int &j, int &kk, int &Y) -> int {
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         int side, j, kk, Y;
         if (xe_slot(m, side, j, kk, Y) >= 0) {
           const int nid = tile_id + (side == 0 ? -1 : 1);
-          const double *slab = (side == 0 ? tp.xr : tp.xl) + int64_t(nid) * NBM * tp.zp * tp.tY;
+          const real_t *slab = (side == 0 ? tp.xr : tp.xl) + int64_t(nid) * NBM * tp.zp * tp.tY;
           xe[m] = slab[(j * tp.zp + P * layer + kk) * tp.tY + Y];
         }
       }
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
       for (int x = 0; x < N; ++x)
-        if (constrained<P>(pm, y, x)) PA[y * N + x] = 0.0;
+        if (constrained<P>(pm, y, x)) PA[y * N + x] = real_t(0);
     }
 
     STFEM_LAYER_BARRIER(); // all waves are done with the transpose slabs: the region becomes `acc`
@@ -377,20 +385,20 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       const bool divert_lane = odd && (X == 0 || (X == XEXT && !t.last_x));
       const unsigned lane_goff = X + prm.nx * (lane_s >> 5), lane_zoff = X + tp.tX * (lane_s >> 5);
       const int lane_aoff = hw * TX + X;
-      double *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
+      real_t *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
       STFEM_UNROLL
       for (int j = 0; j < NBM; ++j) {
         if (j >= prm.nbo) continue;
-        double sv[N][NOF];
+        real_t sv[N][NOF];
         STFEM_UNROLL
         for (int kk = 0; kk < N; ++kk)
           STFEM_UNROLL
         for (int o = 0; o < NOF; ++o) {
           const bool row_ok = (YMAX % 8 == 0) || hw + 8 * o < YMAX;
-          sv[kk][o] = ((kk < P || last_layer) && row_ok && x_lane) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : 0.0;
+          sv[kk][o] = ((kk < P || last_layer) && row_ok && x_lane) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : real_t(0);
         }
-        double *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u) + plane_stride * (int64_t(P) * layer);
-        double *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
+        real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u) + plane_stride * (int64_t(P) * layer);
+        real_t *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
         STFEM_UNROLL
         for (int kk = 0; kk < P; ++kk)
           STFEM_UNROLL
@@ -398,20 +406,20 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
           const int Y = hw + 8 * o;
           const bool row_ok = (YMAX % 8 == 0) || Y < YMAX;
           if (row_ok && x_lane) {
-            double *d = dj + plane_stride * kk + int64_t(o * 8) * prm.nx + lane_goff;
+            real_t *d = dj + plane_stride * kk + int64_t(o * 8) * prm.nx + lane_goff;
             if (odd && divert_lane) xs[kk * tp.tY + Y] = sv[kk][o];
             else if (ADD) *d += sv[kk][o];
             else *d = sv[kk][o];
           }
         }
         if (last_layer) { // the top plane leaves too: to the z-halo slab, or to dst on the last chunk
-          double *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+          real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
           STFEM_UNROLL
           for (int o = 0; o < NOF; ++o) {
             const int Y = hw + 8 * o;
             const bool row_ok = (YMAX % 8 == 0) || Y < YMAX;
             if (row_ok && x_lane) {
-              double *d = dj + plane_stride * P + int64_t(o * 8) * prm.nx + lane_goff;
+              real_t *d = dj + plane_stride * P + int64_t(o * 8) * prm.nx + lane_goff;
               if (!t.last_z) (zj + o * 8 * tp.tX)[lane_zoff] = sv[P][o];
               else if (odd && divert_lane) xs[P * tp.tY + Y] = sv[P][o];
               else if (ADD) *d += sv[P][o];
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       const int hw = 2 * wave_u + (lane_s >> 5), X = lane_s & 31;
       const bool x_lane = X <= xext;
       const bool divert_lane = odd && (X == 0 || (X == xext && !t.last_x));
-      double *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
+      real_t *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
       const unsigned lane_goff = X + prm.nx * (lane_s >> 5), lane_zoff = X + tp.tX * (lane_s >> 5);
       const int lane_aoff = hw * TX + X;
       STFEM_UNROLL
@@ -449,26 +457,26 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         // all LDS reads of this block first, then all stores: a VMEM store keeps its address and
         // data VGPRs locked until it has completed (vmcnt), so they must not be recycled
         // from one store to the next
-        double sv[N][NO];
+        real_t sv[N][NO];
         STFEM_UNROLL
         for (int kk = 0; kk < N; ++kk)
           STFEM_UNROLL
         for (int o = 0; o < NO; ++o)
-          sv[kk][o] = (kk < kend && hw + 8 * o < ymax && x_lane && !(ex & 32)) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : 0.0;
-        double *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u); // wave-uniform
-        double *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+          sv[kk][o] = (kk < kend && hw + 8 * o < ymax && x_lane && !(ex & 32)) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : real_t(0);
+        real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u); // wave-uniform
+        real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
         STFEM_UNROLL
         for (int kk = 0; kk < N; ++kk) {
           if (kk >= kend) continue;
           const int zl = P * layer + kk; // chunk-local plane
           const bool to_zh = kk == P && !t.last_z; // top plane of an inner chunk: z-halo slab
-          double *xs = xslab_out + (j * tp.zp + zl) * tp.tY;
+          real_t *xs = xslab_out + (j * tp.zp + zl) * tp.tY;
           STFEM_UNROLL
           for (int o = 0; o < NO; ++o) {
             const int Y = hw + 8 * o;
             if (ex & 64) { dummy += sv[kk][o]; continue; }
             if (Y < ymax && x_lane) {
-              const double v = sv[kk][o];
+              const real_t v = sv[kk][o];
               if (to_zh) (zj + o * 8 * tp.tX)[lane_zoff] = v;
               else if (divert_lane) xs[Y] = v;
               else if (ADD) (dj + plane_stride * zl + int64_t(o * 8) * prm.nx)[lane_goff] += v;
@@ -503,10 +511,16 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       int n_o = 0;
       STFEM_UNROLL
       for (int o = 0; o < (TY + 7) / 8; ++o) n_o += (2 * wave_u + 8 * o < ymax) ? 1 : 0;
+#ifndef STFEM_F32
       wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
+#else
+      (void)n_o;
+#endif
     }
   }
-  if (dummy == 1.2345e300) tp.zh[0] = dummy; // experiment sink, never true
+#ifdef STFEM_ABLATION
+  if (dummy == real_t(1.2345e30)) tp.zh[0] = dummy; // experiment sink, never true
+#endif
 }
 
 // Adds the halo partial sums of the lower y / z neighbours to the rows a tile owns on its y = 0
@@ -531,22 +545,22 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
   const int XpL = P * tp.cw;            // that column in the left neighbour's coordinates
   const int tid_y = id - tp.ntx, tid_z = id - tp.ntx * tp.nty, tid_yz = tid_z - tp.ntx;
   for (int j = 0; j < prm.nbo; ++j) {
-    double *d = prm.dst[j] + g0;
+    real_t *d = prm.dst[j] + g0;
     const int64_t sy = tp.zp * tp.tX, sz = tp.tY * tp.tX;
-    const double *yh_y = tp.yh + (int64_t(tid_y) * nbm + j) * sy;   // (tx, ty-1, tc)
-    const double *yh_yz = tp.yh + (int64_t(tid_yz) * nbm + j) * sy; // (tx, ty-1, tc-1)
-    const double *zh_z = tp.zh + (int64_t(tid_z) * nbm + j) * sz;   // (tx, ty, tc-1)
+    const real_t *yh_y = tp.yh + (int64_t(tid_y) * nbm + j) * sy;   // (tx, ty-1, tc)
+    const real_t *yh_yz = tp.yh + (int64_t(tid_yz) * nbm + j) * sy; // (tx, ty-1, tc-1)
+    const real_t *zh_z = tp.zh + (int64_t(tid_z) * nbm + j) * sz;   // (tx, ty, tc-1)
     // the same slabs of the tiles at tx - 1 (one tile earlier in the numbering)
     const int64_t left_y = int64_t(nbm) * sy, left_z = int64_t(nbm) * sz;
     if (has_y) // rows Y = 0, Z >= (has_z ? 1 : 0): contributions of the tiles below in y
       for (int Z = rg + has_z; Z < Zn; Z += 8) {
-        double s = yh_y[Z * tp.tX + X];
+        real_t s = yh_y[Z * tp.tX + X];
         if (dxn) s += (yh_y - left_y)[Z * tp.tX + XpL];
         d[plane_stride * Z] += s;
       }
     if (has_z) // plane Z = 0: tiles below in z, and for its row Y = 0 also below in y
       for (int Y = rg; Y < Yn; Y += 8) {
-        double s = zh_z[Y * tp.tX + X];
+        real_t s = zh_z[Y * tp.tX + X];
         if (dxn) s += (zh_z - left_z)[Y * tp.tX + XpL];
         if (Y == 0 && has_y) {
           s += yh_y[X] + yh_yz[P * tp.lz * tp.tX + X];
@@ -609,9 +623,9 @@ __global__ __launch_bounds__(256) void build_metric_kernel(int n, int ncx, int n
                                                             const double *__restrict__ vert,
                                                             const double *__restrict__ xq,
                                                             const double *__restrict__ wq,
-                                                            const double *__restrict__ cl, int cl_layout,
-                                                            const double *__restrict__ cm, int cm_layout,
-                                                            double *__restrict__ metric)
+                                                            const real_t *__restrict__ cl, int cl_layout,
+                                                            const real_t *__restrict__ cm, int cm_layout,
+                                                            real_t *__restrict__ metric)
 {
   const int n3 = n * n * n;
   const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -651,20 +665,20 @@ __global__ __launch_bounds__(256) void build_metric_kernel(int n, int ncx, int n
   const double JxW = det * wq[qx] * wq[qy] * wq[qz];
   const double fl = cl_layout == 0 ? 1.0 : (cl_layout == 1 ? cl[cell] : cl[gid]);
   const double fm = cm_layout == 0 ? 1.0 : (cm_layout == 1 ? cm[cell] : cm[gid]);
-  double *m = metric + (cell * n3 + q) * 8; // one 64-byte record per quadrature point
+  real_t *m = metric + (cell * n3 + q) * 8; // one 64-byte record per quadrature point
   int comp = 0;
   for (int e = 0; e < 3; ++e)
     for (int f = e; f < 3; ++f, ++comp)
-      m[comp] = fl * JxW * (Ji[e][0] * Ji[f][0] + Ji[e][1] * Ji[f][1] + Ji[e][2] * Ji[f][2]);
-  m[6] = fm * JxW;
-  m[7] = 0.0;
+      m[comp] = real_t(fl * JxW * (Ji[e][0] * Ji[f][0] + Ji[e][1] * Ji[f][1] + Ji[e][2] * Ji[f][2]));
+  m[6] = real_t(fm * JxW);
+  m[7] = real_t(0);
 }
 
 } // namespace
 
 int launch_build_metric(int p, const int nc[3], const double *d_vertices, const double *d_xq,
-                        const double *d_wq, const double *coef_lap, int lap_layout,
-                        const double *coef_mass, int mass_layout, double *d_metric, void *stream)
+                        const double *d_wq, const real_t *coef_lap, int lap_layout,
+                        const real_t *coef_mass, int mass_layout, real_t *d_metric, void *stream)
 {
   const int n = p + 1;
   const int64_t ncells = int64_t(nc[0]) * nc[1] * nc[2], total = ncells * n * n * n;
@@ -729,4 +743,5 @@ int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *
 const char *cart_tile_name(int, int) { return "st_sweep_cart_tile"; }
 #endif
 
+} // namespace STFEM_PREC
 } // namespace stfem

@@ -14,11 +14,13 @@ std::array<FullMatrix<Number>, 4> get_fe_time_weights(TimeStepType type, unsigne
                                                       unsigned n_timesteps_at_once = 1)
 {
   const unsigned nt = type == TimeStepType::CGP ? r : r + 1, nb = nt * n_timesteps_at_once;
-  std::array<FullMatrix<Number>, 4> w{{FullMatrix<Number>(nb, nb), FullMatrix<Number>(nb, nb),
-                                       FullMatrix<Number>(nb, 1), FullMatrix<Number>(nb, 1)}};
+  std::array<FullMatrix<double>, 4> d{{FullMatrix<double>(nb, nb), FullMatrix<double>(nb, nb),
+                                       FullMatrix<double>(nb, 1), FullMatrix<double>(nb, 1)}};
   const int rc = stfem_fe_time_weights(int(type), int(r), time_step_size, int(n_timesteps_at_once),
-                                       w[0].data(), w[1].data(), w[2].data(), w[3].data());
+                                       d[0].data(), d[1].data(), d[2].data(), d[3].data());
   if (rc != int(nb)) throw Error(rc, "stfem_fe_time_weights");
+  std::array<FullMatrix<Number>, 4> w;
+  for (int k = 0; k < 4; ++k) w[k] = d[k].template cast<Number>();
   return w;
 }
 
@@ -28,12 +30,14 @@ std::array<FullMatrix<Number>, 5> get_fe_time_weights_wave(TimeStepType type, un
                                                            unsigned n_timesteps_at_once = 1)
 {
   const unsigned nt = type == TimeStepType::CGP ? r : r + 1, nb = nt * n_timesteps_at_once;
-  std::array<FullMatrix<Number>, 5> w{{FullMatrix<Number>(nb, nb), FullMatrix<Number>(nb, nb),
-                                       FullMatrix<Number>(nb, 1), FullMatrix<Number>(nb, 1),
-                                       FullMatrix<Number>(nb, 1)}};
+  std::array<FullMatrix<double>, 5> d{{FullMatrix<double>(nb, nb), FullMatrix<double>(nb, nb),
+                                       FullMatrix<double>(nb, 1), FullMatrix<double>(nb, 1),
+                                       FullMatrix<double>(nb, 1)}};
   const int rc = stfem_fe_time_weights_wave(int(type), int(r), time_step_size, int(n_timesteps_at_once),
-                                            w[0].data(), w[1].data(), w[2].data(), w[3].data(), w[4].data());
+                                            d[0].data(), d[1].data(), d[2].data(), d[3].data(), d[4].data());
   if (rc != int(nb)) throw Error(rc, "stfem_fe_time_weights_wave");
+  std::array<FullMatrix<Number>, 5> w;
+  for (int k = 0; k < 5; ++k) w[k] = d[k].template cast<Number>();
   return w;
 }
 

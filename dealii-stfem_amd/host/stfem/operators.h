@@ -8,6 +8,7 @@
 #include "types.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace stfem {
 
@@ -92,7 +93,7 @@ private:
     md.vertices = mesh.vertices.empty() ? nullptr : mesh.vertices.data();
     md.dirichlet_mask = mesh.dirichlet_mask;
     md.device = mesh.device;
-    stfem_space_desc sd{int32_t(degree), int32_t(degree + 1), 1};
+    stfem_space_desc sd{int32_t(degree), int32_t(degree + 1), 1, std::is_same<Number, float>::value ? 1 : 0};
     stfem_ctx *c = nullptr;
     check(stfem_ctx_create(&md, &sd, &c), "stfem_ctx_create");
     return std::make_shared<Context>(c);
@@ -156,7 +157,13 @@ public:
 private:
   void apply(BlockVectorType &dst, const BlockVectorType &src, int transpose, int add, void *stream) const
   {
-    check(stfem_st_vmult(K.context()->h, int(Alpha.m()), int(Alpha.n()), Alpha.data(), Beta.data(), transpose, add,
+    // the C-ABI takes the temporal matrices in double whatever the operator's Number is
+    std::vector<double> a(size_t(Alpha.m()) * Alpha.n()), b(a.size());
+    for (size_t i = 0; i < a.size(); ++i) {
+      a[i] = double(Alpha.data()[i]);
+      b[i] = double(Beta.data()[i]);
+    }
+    check(stfem_st_vmult(K.context()->h, int(Alpha.m()), int(Alpha.n()), a.data(), b.data(), transpose, add,
                          dst.handle(), src.handle(), stream),
           "SystemMatrix::vmult");
   }
@@ -172,7 +179,9 @@ template <typename Number>
 void tensorproduct_add(const std::shared_ptr<Context> &ctx, BlockVectorT<Number> &c, const FullMatrix<Number> &A,
                        const BlockVectorT<Number> &b, void *stream = nullptr)
 {
-  check(stfem_tensorproduct_add(ctx->h, int(A.m()), int(A.n()), A.data(), c.handle(), b.handle(), stream),
+  std::vector<double> a(size_t(A.m()) * A.n());
+  for (size_t i = 0; i < a.size(); ++i) a[i] = double(A.data()[i]);
+  check(stfem_tensorproduct_add(ctx->h, int(A.m()), int(A.n()), a.data(), c.handle(), b.handle(), stream),
         "tensorproduct_add");
 }
 

@@ -1,7 +1,8 @@
 // Host-side mirror of the reference's vector types (include/types.h:19-36) on top of the C-ABI.
 // VectorT<Number>  ~ dealii::LinearAlgebra::distributed::Vector<Number>      (one spatial vector)
 // BlockVectorT     ~ dealii::LinearAlgebra::distributed::BlockVector<Number> (one per temporal DoF)
-// Only Number = double is built on the device in this round.
+// Number = double (solver) and Number = float (multigrid levels) are both built on the device;
+// host-side copies always go through double (the C-ABI converts for fp32 contexts).
 #pragma once
 #include "../../../include/stfem.h"
 
@@ -39,6 +40,12 @@ public:
   }
   const Number *data() const { return v_.data(); }
   Number *data() { return v_.data(); }
+  template <typename N2> FullMatrix<N2> cast() const
+  {
+    FullMatrix<N2> r(m_, n_);
+    for (size_t i = 0; i < v_.size(); ++i) r.data()[i] = N2(v_[i]);
+    return r;
+  }
 
 private:
   unsigned m_ = 0, n_ = 0;
@@ -57,7 +64,6 @@ struct Context {
 template <typename Number> class BlockVectorT;
 
 template <typename Number> class VectorT {
-  static_assert(sizeof(Number) == sizeof(double), "device path is built for double");
 
 public:
   VectorT() = default;
@@ -69,14 +75,14 @@ public:
     v_.reset(v, stfem_vector_destroy);
   }
   size_t size() const { return ctx_ ? size_t(stfem_n_dofs(ctx_->h)) : 0; }
-  void copy_from_host(const std::vector<Number> &h)
+  void copy_from_host(const std::vector<double> &h)
   {
     const double *p[1] = {h.data()};
     check(stfem_vector_upload(v_.get(), p), "stfem_vector_upload");
   }
-  std::vector<Number> copy_to_host() const
+  std::vector<double> copy_to_host() const
   {
-    std::vector<Number> h(size());
+    std::vector<double> h(size());
     double *p[1] = {h.data()};
     check(stfem_vector_download(v_.get(), p), "stfem_vector_download");
     return h;
@@ -102,15 +108,15 @@ public:
   }
   unsigned n_blocks() const { return nb_; }
   size_t block_size() const { return ctx_ ? size_t(stfem_n_dofs(ctx_->h)) : 0; }
-  void copy_from_host(const std::vector<std::vector<Number>> &h)
+  void copy_from_host(const std::vector<std::vector<double>> &h)
   {
     std::vector<const double *> p;
     for (const auto &b : h) p.push_back(b.data());
     check(stfem_vector_upload(v_.get(), p.data()), "stfem_vector_upload");
   }
-  std::vector<std::vector<Number>> copy_to_host() const
+  std::vector<std::vector<double>> copy_to_host() const
   {
-    std::vector<std::vector<Number>> h(nb_, std::vector<Number>(block_size()));
+    std::vector<std::vector<double>> h(nb_, std::vector<double>(block_size()));
     std::vector<double *> p;
     for (auto &b : h) p.push_back(b.data());
     check(stfem_vector_download(v_.get(), p.data()), "stfem_vector_download");

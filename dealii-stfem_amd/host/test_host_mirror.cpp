@@ -1,7 +1,7 @@
 // C++ caller written against the reference's operator interface (tests/tp_01.cc:112-168 style):
 // builds K, M, the temporal matrices and a SystemMatrix, applies vmult / Tvmult / vmult_slice on the
 // GPU and prints checksums that the pytest driver compares against the CPU oracle.
-// Usage: test_host_mirror <degree> <ncx> <ncy> <ncz> <time type 0|1> <r> <nsteps> <out.bin>
+// Usage: test_host_mirror <degree> <ncx> <ncy> <ncz> <time type 0|1> <r> <nsteps> <out.bin> [float]
 #include "stfem/operators.h"
 
 #include <cstdio>
@@ -10,7 +10,15 @@
 
 using namespace stfem;
 
+template <typename Number> int run(int argc, char **argv);
+
 int main(int argc, char **argv)
+{
+  if (argc >= 10 && std::string(argv[9]) == "float") return run<float>(argc, argv);
+  return run<double>(argc, argv);
+}
+
+template <typename Number> int run(int argc, char **argv)
 {
   if (argc < 9) {
     std::fprintf(stderr, "usage: %s degree ncx ncy ncz type r nsteps out.bin\n", argv[0]);
@@ -22,7 +30,6 @@ int main(int argc, char **argv)
   const auto type = std::atoi(argv[5]) == 0 ? TimeStepType::CGP : TimeStepType::DG;
   const unsigned r = std::atoi(argv[6]), nsteps = std::atoi(argv[7]);
   try {
-    using Number = double;
     MatrixFreeOperatorScalar<3, Number> K_mf(mesh, degree, 0.0, 1.0);
     MatrixFreeOperatorScalar<3, Number> M_mf(K_mf, 1.0, 0.0);
     auto [Alpha, Beta, Gamma, Zeta] = get_fe_time_weights<Number>(type, r, 1.0 / 32, nsteps);

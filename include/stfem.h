@@ -62,6 +62,9 @@ typedef struct {
   int32_t degree;       /* p, 1..4 */
   int32_t n_q_points_1d; /* must be degree+1 */
   int32_t n_components; /* must be 1 (scalar path) */
+  int32_t precision;    /* 0 = fp64 (the solver's Number, operators.cc:5-45), 1 = fp32 (the multigrid
+                           levels' NumberPreconditioner, tests/tp_01.cc:780, 801-806): element type of
+                           all device vectors, coefficients and metric terms of this context */
 } stfem_space_desc;
 
 /* MatrixFreeOperator ctor (include/operators.h:973-1004): builds device tables. Synchronous. */
@@ -72,6 +75,8 @@ int64_t stfem_n_dofs(const stfem_ctx *ctx);
 int64_t stfem_n_cells(const stfem_ctx *ctx);
 /* 1 if the mesh was recognised as an axis-aligned uniform box (Cartesian fast path) */
 int stfem_is_cartesian(const stfem_ctx *ctx);
+/* 0 = fp64, 1 = fp32: the Number type of the operator (MatrixFreeOperator<dim, n_components, Number>) */
+int stfem_ctx_precision(const stfem_ctx *ctx);
 
 /* MatrixFreeOperator::evaluate_coefficient (operators.h:1060-1087).
  * which: 0 = mass coefficient (the M operator), 1 = laplace coefficient (the K operator).
@@ -81,7 +86,7 @@ int stfem_is_cartesian(const stfem_ctx *ctx);
 int stfem_set_coefficient(stfem_ctx *ctx, int which, int layout, const double *host_values);
 
 /* initialize_dof_vector (operators.h:1006-1011, 648-662): n_blocks spatial vectors of
- * stfem_n_dofs doubles each, zero-initialised. */
+ * stfem_n_dofs elements of the context's Number type each, zero-initialised. */
 int stfem_vector_create(stfem_ctx *ctx, int n_blocks, stfem_vec **out);
 /* View caller-owned device memory (e.g. the arrays behind a deal.II
  * LinearAlgebra::distributed::BlockVector<double, MemorySpace::Default>): one device pointer
@@ -90,7 +95,8 @@ int stfem_vector_wrap(stfem_ctx *ctx, int n_blocks, void *const *device_blocks, 
 void stfem_vector_destroy(stfem_vec *v);
 int stfem_vector_n_blocks(const stfem_vec *v);
 void *stfem_vector_block(const stfem_vec *v, int block); /* device pointer */
-/* host <-> device copies of all blocks (host_blocks[b] has stfem_n_dofs doubles). Synchronous. */
+/* host <-> device copies of all blocks (host_blocks[b] has stfem_n_dofs doubles; fp32 contexts
+ * convert on the way). Synchronous. */
 int stfem_vector_upload(stfem_vec *v, const double *const *host_blocks);
 int stfem_vector_download(const stfem_vec *v, double *const *host_blocks);
 

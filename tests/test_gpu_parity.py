@@ -291,3 +291,55 @@ def test_diagonal_with_cell_coefficient_vs_oracle(stfem, oracle_mod):
     orc = oracle_mod.Oracle(p, nc, verts, 63)
     orc.set_coefficient(1, np.repeat(coef[:, None], (p + 1) ** 3, axis=1))
     assert rel(op.compute_diagonal().download()[0], orc.diagonal(mass=0.5, laplace=1.0)) < TOL
+
+
+# ----------------------------------------------------------------------------- fp32 instantiation
+# The reference instantiates the path for float as well (include/operators.cc:5-45) and runs the
+# whole multigrid preconditioner in it (tests/tp_01.cc:780, 801-806).  Tolerance: 1e-5 rel-L2
+# against the fp64 oracle.
+TOL32 = 1e-5
+
+
+def apply32(stfem, ctx, Alpha, Beta, X, transpose=False):
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    nsrc = Alpha.shape[0] if transpose else Alpha.shape[1]
+    ndst = Alpha.shape[1] if transpose else Alpha.shape[0]
+    src = stfem.BlockVector(ctx, nsrc).upload(X)
+    dst = stfem.BlockVector(ctx, ndst)
+    (A.Tvmult if transpose else A.vmult)(dst, src)
+    return dst.download()
+
+
+@pytest.mark.parametrize("name", CART_FIXTURES + GENERAL_FIXTURES)
+def test_fp32_golden_fixture(name, stfem, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ctx = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"],
+                                   dirichlet_mask=int(g["mask"]), number="float")
+    assert stfem.lib().stfem_ctx_precision(ctx._h) == 1
+    if "coef_lap" in g.files:
+        ctx.evaluate_coefficient(g["coef_lap"], which=1)
+    assert rel(apply32(stfem, ctx, g["Alpha"], g["Beta"], g["X"]), g["Y"]) < TOL32
+    assert rel(apply32(stfem, ctx, g["Alpha"], g["Beta"], g["X"], transpose=True), g["YT"]) < TOL32
+    d = stfem.MatrixFreeOperator(int(g["p"]), g["ncell"], vertices=g["vertices"], dirichlet_mask=int(g["mask"]),
+                                 mass_matrix_scaling=1.0, number="float").compute_diagonal().download()[0]
+    assert rel(d, g["diagM"]) < TOL32
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6]],
+                         ids=lambda c: f"f32-Q{c[0]}-{c[5]}{c[6]}x{c[7]}")
+def test_fp32_vs_oracle(case, stfem, oracle_mod):
+    p, nc, lo, up, mask, tt, r, ns, tau = case
+    t = stfem.CGP if tt == "CGP" else stfem.DG
+    Alpha, Beta, Gamma, Zeta = stfem.get_fe_time_weights(t, r, tau, ns)
+    verts = stfem.mesh_vertices(nc, lo, up)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts, dirichlet_mask=mask, number="float")
+    orc = oracle_mod.Oracle(p, nc, verts, mask)
+    X = random_blocks(Alpha.shape[0], ctx.n_dofs)
+    assert rel(apply32(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL32
+    assert rel(apply32(stfem, ctx, Alpha, Beta, X, transpose=True),
+               orc.st_vmult(Alpha, Beta, X, transpose=True)) < TOL32
+    # BLAS-1 in the context's precision, dot accumulated in double
+    a = stfem.BlockVector(ctx, 1).upload(X[:1]); b = stfem.BlockVector(ctx, 1).upload(X[:1])
+    stfem.tensorproduct_add(ctx, a, np.array([[0.5]]), b)
+    assert rel(a.download(), 1.5 * X[:1]) < 1e-6
+    assert abs(stfem.dot(ctx, b, b) - np.sum(X[:1].astype(np.float32).astype(np.float64) ** 2)) < 1e-6 * np.sum(X[:1] ** 2)
