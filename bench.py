@@ -64,7 +64,7 @@ def measured_traffic(kernel_name):
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("kernel") != kernel_name:
+        if not kernel_name.startswith(t.get("kernel", "?")) or "f32" in kernel_name:
             return None
         return 1024.0 * (2.0 * t["fetch_kb_per_vmult"] + t["write_kb_per_vmult"])
     except (OSError, KeyError, ValueError):
@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--time-degree", type=int, default=2)
     ap.add_argument("--distort", type=float, default=0.0,
                     help="interior-vertex jitter in units of h (0.15 = BASELINE configs[2] mesh); 0 = Cartesian")
+    ap.add_argument("--number", choices=["double", "float"], default="double",
+                    help="operator Number type: double (headline) or float (the reference's multigrid-level precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=16)
     args = ap.parse_args()
@@ -116,11 +118,11 @@ def main():
     if args.distort:
         verts = stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, float(world)), args.distort, 5489,
                                     z_range=(slab.z0, slab.z1))
-        ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=verts,
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=verts, number=args.number,
                                        dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
     else:
         ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=(0, 0, float(slab.z0) / n),
-                                       upper=(1, 1, float(slab.z1) / n),
+                                       upper=(1, 1, float(slab.z1) / n), number=args.number,
                                        dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
     A = stfem.SystemMatrix(ctx, Alpha, Beta)
     ndofs = ctx.n_dofs
@@ -130,11 +132,13 @@ def main():
     # synthetic data, resident in HBM before the timed region (torch = device-memory plumbing)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    src_t = torch.rand((nb, ndofs), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
-    dst_t = torch.zeros((nb, ndofs), dtype=torch.float64, device=dev)
+    tdt = torch.float64 if args.number == "double" else torch.float32
+    esz = 8 if args.number == "double" else 4
+    src_t = torch.rand((nb, ndofs), dtype=tdt, device=dev, generator=gen) * 2 - 1
+    dst_t = torch.zeros((nb, ndofs), dtype=tdt, device=dev)
     src = stfem.BlockVector(ctx, device_ptrs=[src_t[b].data_ptr() for b in range(nb)])
     dst = stfem.BlockVector(ctx, device_ptrs=[dst_t[b].data_ptr() for b in range(nb)])
-    bufs = {k: torch.zeros(nb * plane, dtype=torch.float64, device=dev) for k in ("ts", "bs", "tr", "br")}
+    bufs = {k: torch.zeros(nb * plane, dtype=tdt, device=dev) for k in ("ts", "bs", "tr", "br")}
     L = stfem.lib()
     nz_local = p * (slab.z1 - slab.z0) + 1
 
@@ -153,7 +157,7 @@ def main():
         if slab.has_lower:
             dist.send(src_t[:, :plane].contiguous(), rank - 1)
         if slab.has_upper:
-            g = torch.empty((nb, plane), dtype=torch.float64, device=dev)
+            g = torch.empty((nb, plane), dtype=tdt, device=dev)
             dist.recv(g, rank + 1)
             src_t[:, -plane:] = g
 
@@ -202,7 +206,7 @@ def main():
 
     if rank == 0:
         # 16 B per space-time DoF per vmult (8 B src read + 8 B dst write)
-        alg_bytes = 16.0 * nb * ndofs
+        alg_bytes = 2.0 * esz * nb * ndofs  # fp64: 16 B per DoF; fp32: 8 B
         achieved = alg_bytes / (kms * 1e-3) / 1e9
         out = {
             "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s",
@@ -210,7 +214,7 @@ def main():
             "unit": "space-time DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if args.number == "double" else "f32", "data": "synthetic",
             "config": {"workload": f"3D heat, Q{p} x cG({r}), {n}x{n}x{n * world} cells "
                                    + (f"perturbed ({args.distort} h vertex jitter)" if args.distort else "Cartesian")
                                    + f" slab mesh, {total_dofs} space-time DoFs"
@@ -220,7 +224,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(ctx.last_kernel_name)
-                         if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else None,
+                         if (world, n, p, r, args.distort, args.number) == (1, 72, 4, 2, 0.0, "double") else None,
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

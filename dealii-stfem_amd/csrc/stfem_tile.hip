@@ -389,31 +389,39 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       STFEM_UNROLL
       for (int j = 0; j < NBM; ++j) {
         if (j >= prm.nbo) continue;
+        // all LDS reads of this block first (unconditionally: every index stays inside the slab),
+        // then all stores under ONE lane predicate
         real_t sv[N][NOF];
         STFEM_UNROLL
         for (int kk = 0; kk < N; ++kk)
           STFEM_UNROLL
-        for (int o = 0; o < NOF; ++o) {
-          const bool row_ok = (YMAX % 8 == 0) || hw + 8 * o < YMAX;
-          sv[kk][o] = ((kk < P || last_layer) && row_ok && x_lane) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : real_t(0);
-        }
+        for (int o = 0; o < NOF; ++o) sv[kk][o] = acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX];
         real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u) + plane_stride * (int64_t(P) * layer);
-        real_t *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
-        STFEM_UNROLL
-        for (int kk = 0; kk < P; ++kk)
+        const bool main_lane = x_lane && !(odd && divert_lane);
+        if (main_lane) {
           STFEM_UNROLL
-        for (int o = 0; o < NOF; ++o) {
-          const int Y = hw + 8 * o;
-          const bool row_ok = (YMAX % 8 == 0) || Y < YMAX;
-          if (row_ok && x_lane) {
+          for (int kk = 0; kk < P; ++kk)
+            STFEM_UNROLL
+          for (int o = 0; o < NOF; ++o) {
+            if ((YMAX % 8 != 0) && hw + 8 * o >= YMAX) continue;
             real_t *d = dj + plane_stride * kk + int64_t(o * 8) * prm.nx + lane_goff;
-            if (odd && divert_lane) xs[kk * tp.tY + Y] = sv[kk][o];
-            else if (ADD) *d += sv[kk][o];
+            if (ADD) *d += sv[kk][o];
             else *d = sv[kk][o];
+          }
+        }
+        if (odd && divert_lane) { // the two shared columns of an odd tile go to its x-slabs
+          real_t *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
+          STFEM_UNROLL
+          for (int kk = 0; kk < P; ++kk)
+            STFEM_UNROLL
+          for (int o = 0; o < NOF; ++o) {
+            const int Y = hw + 8 * o;
+            if ((YMAX % 8 == 0) || Y < YMAX) xs[kk * tp.tY + Y] = sv[kk][o];
           }
         }
         if (last_layer) { // the top plane leaves too: to the z-halo slab, or to dst on the last chunk
           real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+          real_t *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
           STFEM_UNROLL
           for (int o = 0; o < NOF; ++o) {
             const int Y = hw + 8 * o;
@@ -607,8 +615,13 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
 
 template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePlan &tp, hipStream_t st)
 {
+#ifdef STFEM_F32
+  // half the registers and half the LDS per workgroup: twice the waves per SIMD
+  return launch_tile_w<P, NBM, 4>(prm, tp, st);
+#else
   static const int minw = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 2;
   return minw == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
+#endif
 }
 
 } // namespace

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for PMC in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed"
   find $OUT/p$i -name "*counter_collection.csv" -exec cp {} $OUT/pmc$i.csv \;
 done
 python3 $ROOT/tools/summarize_pmc.py $OUT | grep -v "^=="
