@@ -221,6 +221,143 @@ static Mat transpose(int n, const Mat &A)
   return T;
 }
 
+namespace {
+
+// Generalised symmetric eigenproblem K v = lam M v of a small dense pair (m <= 4), M SPD:
+// Cholesky M = L L^T, cyclic Jacobi on L^-1 K L^-T.  Returns eigenvalues (ascending) and the
+// M-orthonormal eigenvectors as columns of V (row-major m x m).
+void small_gen_eig(int m, Mat K, Mat M, std::vector<double> &lam, Mat &V)
+{
+  Mat L(size_t(m) * m, 0.0);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = M[i * m + j];
+      for (int k = 0; k < j; ++k) s -= L[i * m + k] * L[j * m + k];
+      L[i * m + j] = i == j ? std::sqrt(s) : s / L[j * m + j];
+    }
+  // Li = L^-1 (lower triangular)
+  Mat Li(size_t(m) * m, 0.0);
+  for (int c = 0; c < m; ++c)
+    for (int i = c; i < m; ++i) {
+      double s = i == c ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= L[i * m + k] * Li[k * m + c];
+      Li[i * m + c] = s / L[i * m + i];
+    }
+  // A = Li K Li^T
+  Mat T(size_t(m) * m, 0.0), A(size_t(m) * m, 0.0);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j)
+      for (int k = 0; k < m; ++k) T[i * m + j] += Li[i * m + k] * K[k * m + j];
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j)
+      for (int k = 0; k < m; ++k) A[i * m + j] += T[i * m + k] * Li[j * m + k];
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < i; ++j) A[i * m + j] = A[j * m + i] = 0.5 * (A[i * m + j] + A[j * m + i]);
+  Mat Q(size_t(m) * m, 0.0);
+  for (int i = 0; i < m; ++i) Q[i * m + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) (i == j ? dia : off) += A[i * m + j] * A[i * m + j];
+    if (off <= 1e-34 * dia) break;
+    for (int pi = 0; pi < m; ++pi)
+      for (int qi = pi + 1; qi < m; ++qi) {
+        if (A[pi * m + qi] == 0.0) continue;
+        const double theta = (A[qi * m + qi] - A[pi * m + pi]) / (2.0 * A[pi * m + qi]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < m; ++k) { // columns p, q
+          const double akp = A[k * m + pi], akq = A[k * m + qi];
+          A[k * m + pi] = c * akp - s * akq;
+          A[k * m + qi] = s * akp + c * akq;
+        }
+        for (int k = 0; k < m; ++k) { // rows p, q
+          const double apk = A[pi * m + k], aqk = A[qi * m + k];
+          A[pi * m + k] = c * apk - s * aqk;
+          A[qi * m + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double qkp = Q[k * m + pi], qkq = Q[k * m + qi];
+          Q[k * m + pi] = c * qkp - s * qkq;
+          Q[k * m + qi] = s * qkp + c * qkq;
+        }
+      }
+  }
+  std::vector<int> order(m);
+  for (int i = 0; i < m; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return A[a * m + a] < A[b * m + b]; });
+  lam.resize(m);
+  V.assign(size_t(m) * m, 0.0);
+  for (int e = 0; e < m; ++e) {
+    const int o = order[e];
+    lam[e] = A[o * m + o];
+    for (int i = 0; i < m; ++i) { // v = L^-T q
+      double s = 0.0;
+      for (int k = 0; k < m; ++k) s += Li[k * m + i] * Q[k * m + o];
+      V[i * m + e] = s;
+    }
+  }
+}
+
+// fills t.fd_W / t.fd_lam (see host_tables.h)
+void make_fast_diagonalisation(ShapeTables &t)
+{
+  const int n = t.n, h = n / 2, ne = n - h;
+  Mat M1(size_t(n) * n, 0.0), K1(size_t(n) * n, 0.0);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b)
+      for (int q = 0; q < n; ++q) {
+        M1[a * n + b] += t.wq[q] * t.S[q * n + a] * t.S[q * n + b];
+        K1[a * n + b] += t.wq[q] * t.D[q * n + a] * t.D[q * n + b];
+      }
+  std::fill(t.fd_W, t.fd_W + EO_MAX, 0.0);
+  std::fill(t.fd_lam, t.fd_lam + 8, 0.0);
+  // parity bases: even e_i = (d_i + d_{n-1-i})/sqrt2 (i < h), middle d_h; odd o_i = (d_i - d_{n-1-i})/sqrt2
+  const double r2 = std::sqrt(0.5);
+  for (int parity = 0; parity < 2; ++parity) {
+    const int m = parity == 0 ? ne : h;
+    if (m == 0) continue;
+    Mat B(size_t(n) * m, 0.0); // basis vectors as columns
+    for (int i = 0; i < m; ++i) {
+      if (parity == 0 && i == h) B[h * m + i] = 1.0; // middle node (odd n only)
+      else {
+        B[i * m + i] = r2;
+        B[(n - 1 - i) * m + i] = parity == 0 ? r2 : -r2;
+      }
+    }
+    Mat Mr(size_t(m) * m, 0.0), Kr(size_t(m) * m, 0.0);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j)
+        for (int a = 0; a < n; ++a)
+          for (int b = 0; b < n; ++b) {
+            Mr[i * m + j] += B[a * m + i] * M1[a * n + b] * B[b * m + j];
+            Kr[i * m + j] += B[a * m + i] * K1[a * n + b] * B[b * m + j];
+          }
+    std::vector<double> lam;
+    Mat Vr;
+    small_gen_eig(m, Kr, Mr, lam, Vr);
+    for (int e = 0; e < m; ++e) {
+      // full eigenvector v = B vr, row of W = (M1 v)^T
+      std::vector<double> v(n, 0.0), w(n, 0.0);
+      for (int a = 0; a < n; ++a)
+        for (int i = 0; i < m; ++i) v[a] += B[a * m + i] * Vr[i * m + e];
+      for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) w[a] += M1[a * n + b] * v[b];
+      // sign convention: first nonzero entry positive (deterministic tables)
+      const double sg = w[0] < 0 ? -1.0 : 1.0;
+      if (parity == 0) {
+        for (int i = 0; i < ne; ++i) t.fd_W[e * ne + i] = sg * w[i];
+        t.fd_lam[e] = lam[e];
+      } else {
+        for (int i = 0; i < h; ++i) t.fd_W[ne * ne + e * h + i] = sg * w[i];
+        t.fd_lam[ne + e] = lam[e];
+      }
+    }
+  }
+}
+
+} // namespace
+
 ShapeTables make_shape_tables(int p)
 {
   ShapeTables t;
@@ -252,6 +389,7 @@ ShapeTables make_shape_tables(int p)
   eo_pack(n, transpose(n, t.S), t.eo_ST);
   eo_pack(n, t.Dcol, t.eo_Dq);
   eo_pack(n, transpose(n, t.Dcol), t.eo_DqT);
+  make_fast_diagonalisation(t);
   return t;
 }
 

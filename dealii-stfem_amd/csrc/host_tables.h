@@ -34,6 +34,14 @@ struct ShapeTables {
   double eo_Si[EO_MAX], eo_SiT[EO_MAX], eo_Dc[EO_MAX], eo_DcT[EO_MAX];
   double eo_L[EO_MAX]; // L = Dc^T Dc: 1D weighted collocation Laplacian (symmetric type)
   double eo_S[EO_MAX], eo_ST[EO_MAX], eo_Dq[EO_MAX], eo_DqT[EO_MAX]; // unweighted S, Dcol
+  // Simultaneous diagonalisation of the 1D nodal mass and stiffness matrices of the reference
+  // cell, M1 = S^T diag(w) S and K1 = D^T diag(w) D:  W M1^-1 W^T = I,  K1 = W^T diag(lam) W
+  // (W = V^-1 for the M1-orthonormal generalised eigenvectors V).  Both matrices are
+  // persymmetric, so every mode is even or odd: rows 0..ne-1 of W are even (ne = ceil(n/2)),
+  // rows ne..n-1 odd.  fd_W packs only the independent half:
+  //   We[m*ne + i], i < ne   (coefficient of u_i + u_{n-1-i}, and of u_{n/2} for the middle)
+  //   Wo[m*h + i],  i < h    (coefficient of u_i - u_{n-1-i}),   h = n/2, stored after We
+  double fd_W[EO_MAX], fd_lam[8];
 };
 ShapeTables make_shape_tables(int p);
 

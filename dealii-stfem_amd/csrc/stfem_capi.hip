@@ -369,6 +369,12 @@ template <class PR> static void fill_common(const stfem_ctx *c, typename PR::Swe
     prm.eo_Dq[i] = real(c->tab.eo_Dq[i]);
     prm.eo_DqT[i] = real(c->tab.eo_DqT[i]);
   }
+  for (int i = 0; i < EO_N; ++i) prm.fd_W[i] = real(c->tab.fd_W[i]);
+  for (int i = 0; i < 8; ++i) {
+    prm.fd_lx[i] = real(c->tab.fd_lam[i] / (c->h[0] * c->h[0]));
+    prm.fd_ly[i] = real(c->tab.fd_lam[i] / (c->h[1] * c->h[1]));
+    prm.fd_lz[i] = real(c->tab.fd_lam[i] / (c->h[2] * c->h[2]));
+  }
 }
 
 // Chooses the z-chunking of the tile variant: enough workgroups to fill 2 per CU several times

@@ -6,9 +6,9 @@
 //     out_j = sum_i alpha(j,i) K_cell u_i + beta(j,i) M_cell u_i
 // i.e. the per-cell body of SystemMatrix::vmult (reference include/operators.h:536-559) around
 // MatrixFreeOperator::do_cell_integral_local (operators.h:1135-1173), restructured: the temporal
-// combination commutes with the spatial interpolation, so it is applied once to the
-// x/y-interpolated data and the K and M parts share one evaluate/integrate pipeline
-// (10 one-dimensional sweeps per output block instead of 2 x 12 per input block).
+// combination commutes with the spatial transforms, so the K and M parts of all blocks share one
+// pipeline (Cartesian cells: 7 one-dimensional sweeps per output block, see cell_core; general
+// cells: 13, see cell_core_general; the reference needs 2 x 12 per input block).
 #pragma once
 #include "stfem_device.h"
 #include "stfem_kernels.h"
@@ -28,9 +28,19 @@ template <int P, int NBM> struct Geometry {
   static constexpr int LDS_PER_WAVE = CELLS_PER_WAVE * NBM * CBS;
 };
 
-// One pass of the fused operator over the cells owned by this wave.
+// One pass of the fused operator over the cells owned by this wave (Cartesian cells, coefficient
+// constant in the cell).
 // PA: on entry the nodal src plane (layout A, [y][x]) of (cell, input block blk, z-plane k),
 //     on exit the nodal result plane of (cell, output block blk, z-plane k).
+//
+// With exact Gauss quadrature the cell matrices are Kronecker products of the 1D nodal mass and
+// stiffness matrices M1, K1, which are diagonalised simultaneously (K1 = W^T Lam W, M1 = W^T W):
+//   sum_i (aK_i K_cell + aM_i M_cell) u_i
+//     = (W^T x W^T x W^T) [ sum_i (aK_i (lx_a + ly_b + lz_c) + aM_i) (W x W x W) u_i ]
+// i.e. three transforms to modal space, a diagonal scaling that also carries the temporal
+// combination, three transforms back: 7 one-dimensional sweeps (8 for more than two blocks) and
+// two wave-private transposes, against 10 sweeps and four transposes of the quadrature form
+// of do_cell_integral_local (operators.h:1135-1173); identical up to rounding.
 template <int P, int NBM>
 __device__ __forceinline__ void
 cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, int blk, int k,
@@ -48,9 +58,9 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
 #endif
   if (no_lds) { in_active = false; out_active = false; }
 
-  // ---- phase A: interpolate x, y (registers), hand over to layout B
-  plane_sweep<N, +1, true>(prm.eo_Si, PA);
-  plane_sweep<N, +1, false>(prm.eo_Si, PA);
+  // ---- phase A: to modal space in x, y (registers), hand over to layout B
+  fd_plane<N, true, true>(prm.fd_W, PA);
+  fd_plane<N, true, false>(prm.fd_W, PA);
   if (in_active) {
     STFEM_UNROLL
     for (int y = 0; y < N; ++y)
@@ -59,71 +69,62 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
   }
   wave_lds_fence();
 
-  // ---- phase B: temporal combination, interpolate z, mass + y/z Laplacian.
-  // Row by row (fixed y, line along z): combine the input blocks, interpolate both combinations
-  // and apply the z Laplacian while only one line is in flight, so that the peak register need
-  // stays at the two result planes plus one line.
-  real_t Ua[N * N], R[N * N];
+  // ---- phase B (this lane: x-mode k, registers [y-mode][z]): row by row, to modal space in z,
+  // diagonal scaling + temporal combination, back to nodal values in z
+  real_t lxk = prm.fd_lx[0];
+  STFEM_UNROLL
+  for (int m = 1; m < N; ++m) lxk = k == m ? prm.fd_lx[m] : lxk;
+  real_t R[N * N];
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
-    real_t ua[N], ub[N];
-    STFEM_UNROLL
-    for (int z = 0; z < N; ++z) ua[z] = ub[z] = real_t(0);
-    STFEM_UNROLL
-    for (int i = 0; i < NBM; ++i) {
-      if (i < prm.nbi) {
-        const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
-        STFEM_UNROLL
-        for (int z = 0; z < N; ++z) {
-          const real_t v = no_lds ? real_t(1) + z : in_lds[z * N * N + y * N + k];
-          ua[z] = fma(aK[i], v, ua[z]);
-          ub[z] = fma(aM[i], v, ub[z]);
+    const real_t sy = lxk + prm.fd_ly[y];
+    real_t acc[N];
+    if (NBM <= 2) {
+      // transform every input block, combine in modal space
+      STFEM_UNROLL
+      for (int i = 0; i < NBM; ++i) {
+        if (i == 0 || i < prm.nbi) {
+          const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
+          real_t v[N], t[N];
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) v[z] = no_lds ? real_t(1) + z : in_lds[z * N * N + y * N + k];
+          fd_forward<N>(prm.fd_W, v, t);
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) {
+            const real_t d = fma(aK[i], sy + prm.fd_lz[z], aM[i]);
+            acc[z] = i == 0 ? d * t[z] : fma(d, t[z], acc[z]);
+          }
         }
       }
+    } else {
+      // combine first (two combinations), transform both
+      real_t ua[N], ub[N];
+      STFEM_UNROLL
+      for (int z = 0; z < N; ++z) ua[z] = ub[z] = real_t(0);
+      STFEM_UNROLL
+      for (int i = 0; i < NBM; ++i) {
+        if (i < prm.nbi) {
+          const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) {
+            const real_t v = no_lds ? real_t(1) + z : in_lds[z * N * N + y * N + k];
+            ua[z] = fma(aK[i], v, ua[z]);
+            ub[z] = fma(aM[i], v, ub[z]);
+          }
+        }
+      }
+      real_t ta[N], tb[N];
+      fd_forward<N>(prm.fd_W, ua, ta);
+      fd_forward<N>(prm.fd_W, ub, tb);
+      STFEM_UNROLL
+      for (int z = 0; z < N; ++z) acc[z] = fma(sy + prm.fd_lz[z], ta[z], tb[z]);
     }
-    real_t ta[N], tb[N], tl[N];
-    eo_apply<N, +1>(prm.eo_Si, ua, ta);
-    eo_apply<N, +1>(prm.eo_Si, ub, tb);
-    // Cartesian cell, coefficient constant in the cell: D^T c D collapses to c * L (one sweep)
-    eo_apply<N, +1>(prm.eo_L, ta, tl);
+    real_t r[N];
+    fd_backward<N>(prm.fd_W, acc, r);
     STFEM_UNROLL
-    for (int z = 0; z < N; ++z) {
-      Ua[y * N + z] = ta[z];
-      R[y * N + z] = fma(prm.ihz2, tl[z], tb[z]);
-    }
+    for (int z = 0; z < N; ++z) R[y * N + z] = r[z];
   }
-  plane_sweep_acc<N, false>(prm.eo_L, prm.ihy2, Ua, R);
   pin(R);
-  wave_lds_fence();
-  if (out_active) {
-    STFEM_UNROLL
-    for (int y = 0; y < N; ++y)
-      STFEM_UNROLL
-    for (int z = 0; z < N; ++z) cb_lds[z * N * N + y * N + k] = Ua[y * N + z];
-  }
-  wave_lds_fence();
-
-  // ---- phase A2: x Laplacian in layout A
-  STFEM_UNROLL
-  for (int y = 0; y < N; ++y)
-    STFEM_UNROLL
-  for (int x = 0; x < N; ++x) PA[y * N + x] = no_lds ? Ua[y * N + x] : cb_lds[k * N * N + y * N + x];
-  plane_sweep_scaled<N, true>(prm.eo_L, prm.ihx2, PA);
-  wave_lds_fence();
-  if (out_active) {
-    STFEM_UNROLL
-    for (int y = 0; y < N; ++y)
-      STFEM_UNROLL
-    for (int x = 0; x < N; ++x) cb_lds[k * N * N + y * N + x] = PA[y * N + x];
-  }
-  wave_lds_fence();
-
-  // ---- phase B2: collect, integrate z
-  STFEM_UNROLL
-  for (int y = 0; y < N; ++y)
-    STFEM_UNROLL
-  for (int z = 0; z < N; ++z) R[y * N + z] += no_lds ? PA[y * N + z] : cb_lds[z * N * N + y * N + k];
-  plane_sweep_T<N, true>(prm.eo_Si, R);
   wave_lds_fence();
   if (out_active) {
     STFEM_UNROLL
@@ -133,13 +134,13 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
   }
   wave_lds_fence();
 
-  // ---- phase A3: integrate y, x
+  // ---- phase A2: back to nodal values in y, x
   STFEM_UNROLL
   for (int y = 0; y < N; ++y)
     STFEM_UNROLL
   for (int x = 0; x < N; ++x) PA[y * N + x] = no_lds ? R[y * N + x] : cb_lds[k * N * N + y * N + x];
-  plane_sweep_T<N, false>(prm.eo_Si, PA);
-  plane_sweep_T<N, true>(prm.eo_Si, PA);
+  fd_plane<N, false, false>(prm.fd_W, PA);
+  fd_plane<N, false, true>(prm.fd_W, PA);
   wave_lds_fence();
 }
 

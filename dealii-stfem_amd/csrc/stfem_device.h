@@ -210,6 +210,79 @@ __device__ __forceinline__ void plane_sweep_scaled(const real_t *__restrict__ c,
   }
 }
 
+// ---- fast diagonalisation (Cartesian cells, coefficient constant in the cell) ----
+// Modes of the 1D pair (M1, K1) are even or odd (host_tables.h: fd_W), so the transform to
+// modal space needs no recombination of its outputs and the transform back none of its inputs:
+// 4 adds + 13 multiply-adds per line for N = 5, against 8 + 13 of a general even-odd product.
+// y[0..NE) even modes, y[NE..N) odd modes.
+template <int N>
+__device__ __forceinline__ void fd_forward(const real_t *__restrict__ c, const real_t (&x)[N],
+                                           real_t (&y)[N])
+{
+  constexpr int H = N / 2, NE = N - H;
+  real_t xe[NE], xo[H > 0 ? H : 1];
+  STFEM_UNROLL
+  for (int i = 0; i < H; ++i) {
+    xe[i] = x[i] + x[N - 1 - i];
+    xo[i] = x[i] - x[N - 1 - i];
+  }
+  if (N & 1) xe[H] = x[H];
+  STFEM_UNROLL
+  for (int m = 0; m < NE; ++m) {
+    real_t a = c[m * NE] * xe[0];
+    STFEM_UNROLL
+    for (int i = 1; i < NE; ++i) a = fma(c[m * NE + i], xe[i], a);
+    y[m] = a;
+  }
+  STFEM_UNROLL
+  for (int m = 0; m < H; ++m) {
+    real_t b = c[NE * NE + m * H] * xo[0];
+    STFEM_UNROLL
+    for (int i = 1; i < H; ++i) b = fma(c[NE * NE + m * H + i], xo[i], b);
+    y[NE + m] = b;
+  }
+}
+
+// y = W^T x: modal -> nodal
+template <int N>
+__device__ __forceinline__ void fd_backward(const real_t *__restrict__ c, const real_t (&x)[N],
+                                            real_t (&y)[N])
+{
+  constexpr int H = N / 2, NE = N - H;
+  STFEM_UNROLL
+  for (int i = 0; i < H; ++i) {
+    real_t a = c[i] * x[0];
+    STFEM_UNROLL
+    for (int m = 1; m < NE; ++m) a = fma(c[m * NE + i], x[m], a);
+    real_t b = c[NE * NE + i] * x[NE];
+    STFEM_UNROLL
+    for (int m = 1; m < H; ++m) b = fma(c[NE * NE + m * H + i], x[NE + m], b);
+    y[i] = a + b;
+    y[N - 1 - i] = a - b;
+  }
+  if (N & 1) {
+    real_t a = c[H] * x[0];
+    STFEM_UNROLL
+    for (int m = 1; m < NE; ++m) a = fma(c[m * NE + H], x[m], a);
+    y[H] = a;
+  }
+}
+
+template <int N, bool FORWARD, bool ALONG_FAST>
+__device__ __forceinline__ void fd_plane(const real_t *__restrict__ c, real_t (&P)[N * N])
+{
+  STFEM_UNROLL
+  for (int o = 0; o < N; ++o) {
+    real_t x[N], y[N];
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = ALONG_FAST ? P[o * N + i] : P[i * N + o];
+    if (FORWARD) fd_forward<N>(c, x, y);
+    else fd_backward<N>(c, x, y);
+    STFEM_UNROLL
+    for (int i = 0; i < N; ++i) (ALONG_FAST ? P[o * N + i] : P[i * N + o]) = y[i];
+  }
+}
+
 // Orders the LDS traffic of ONE wave: everything this wave wrote before is visible to its
 // later reads.  No instruction is emitted beyond what the compiler needs for its own ordering.
 __device__ __forceinline__ void wave_lds_fence()
@@ -220,6 +293,17 @@ __device__ __forceinline__ void wave_lds_fence()
   // also a scheduling barrier: without it the machine scheduler interleaves all five phases to
   // hide LDS latency and needs > 256 VGPRs (1 wave/SIMD); phase-ordered code needs ~half
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// A zero the compiler cannot see through.  `table + opaque_zero()` makes the scalar loads of a 1D
+// table (kernel argument -> s_load) depend on this program point, so they are re-issued where
+// they are used instead of being hoisted out of the layer loop and held in ~50 SGPRs for the whole
+// kernel - which pushes every lane mask and pointer into VGPR lanes (v_readlane per use).
+__device__ __forceinline__ int opaque_zero()
+{
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
 }
 
 // Pins a register plane at this program point: everything that produces it is scheduled before,

@@ -21,6 +21,9 @@ struct SweepParams {
   const real_t *coef_mass; // per cell or nullptr
   int experiment;          // ablation bits for cell_core (256: no LDS traffic in the core); results wrong if set
   real_t eo_Si[EO_N], eo_L[EO_N]; // even-odd packed: interpolation (weights folded), 1D Laplacian
+  // Cartesian fast path: simultaneous diagonalisation of the 1D nodal mass / stiffness pair
+  // (host_tables.h: fd_W, fd_lam), eigenvalues pre-scaled by 1/h_d^2 per direction
+  real_t fd_W[EO_N], fd_lx[8], fd_ly[8], fd_lz[8];
   // general-geometry path: plain interpolation S, collocation derivative D and D^T, and the
   // per-quadrature-point metric records [cell][qz][qy][qx][8] = (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad)
   real_t eo_S[EO_N], eo_Dq[EO_N], eo_DqT[EO_N];
