@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -71,7 +72,7 @@ int hip_fail(hipError_t e, const char *what)
 } // namespace
 
 struct stfem_ctx {
-  int p = 0, device = 0;
+  int p = 0, device = 0, n_cu = 0;
   int nc[3] = {0, 0, 0}, nd[3] = {0, 0, 0};
   int64_t ndofs = 0, ncells = 0;
   int dmask = 0;
@@ -102,6 +103,17 @@ struct stfem_vec {
   bool owns = false;
   std::vector<void *> blk; // device arrays of the context's element type
 };
+
+namespace stfem {
+int tile_wg_per_cu(int p, int nbm)
+{
+  static const int forced = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 0;
+  if (forced == 2 || forced == 3) return forced;
+  nbm = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
+  (void)p;
+  return 2; // three fit (<= 168 VGPRs) for small p / few blocks, but measured no faster: the kernel is HBM-bound
+}
+} // namespace stfem
 
 extern "C" {
 
@@ -136,6 +148,8 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return STFEM_ERR_NO_DEVICE;
   if (mesh->device < 0 || mesh->device >= ndev) return STFEM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(mesh->device));
+  int n_cu = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, mesh->device) != hipSuccess) n_cu = 0;
 
   stfem_ctx *c = new (std::nothrow) stfem_ctx;
   if (!c) return STFEM_ERR_OUT_OF_MEMORY;
@@ -143,6 +157,7 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
   c->prec = space->precision;
   c->es = c->prec ? sizeof(float) : sizeof(double);
   c->device = mesh->device;
+  c->n_cu = n_cu;
   c->ndofs = c->ncells = 1;
   for (int d = 0; d < 3; ++d) {
     c->nc[d] = mesh->ncell[d];
@@ -377,29 +392,33 @@ template <class PR> static void fill_common(const stfem_ctx *c, typename PR::Swe
   }
 }
 
-// Chooses the z-chunking of the tile variant: enough workgroups to fill 2 per CU several times
-// over, chunks long enough that the z-halo stays small.
-template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp)
+// Chooses the z-chunking of the tile variant.  One colour launch has columns x ntc workgroups of
+// ceil(ncz / ntc) layers (+ about one layer of start-up) that run in rounds of `slots` resident
+// workgroups; a layer takes about as long with three workgroups on a CU as with two, so what
+// matters is that the last round is full.  Fewer chunks win ties (smaller z-halo).
+template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm)
 {
   tp.ntx = (c->nc[0] + tp.cw - 1) / tp.cw;
   tp.nty = (c->nc[1] + tp.rows - 1) / tp.rows;
   const int ncz = c->nc[2];
-  int lz;
+  int ntc = 1;
   if (const char *e = getenv("STFEM_TILE_LZ")) {
-    lz = std::max(1, std::min(ncz, atoi(e)));
+    const int lz = std::max(1, std::min(ncz, atoi(e)));
+    ntc = (ncz + lz - 1) / lz;
   } else {
-    const int64_t columns = int64_t(tp.ntx) * tp.nty, target = 4 * 512;
-    int ntc = int(std::max<int64_t>(1, std::min<int64_t>((target + columns / 2) / columns, std::max(1, ncz / 2))));
-    lz = (ncz + ntc - 1) / ntc;
-    // prefer a divisor of ncz nearby (equal chunks, no ragged tail)
-    for (int d = 0; d <= lz / 4; ++d) {
-      if (lz + d <= ncz && ncz % (lz + d) == 0) { lz += d; break; }
-      if (lz - d >= 1 && ncz % (lz - d) == 0) { lz -= d; break; }
+    const int wpc = std::max(1, (c->prec ? 4 : stfem::tile_wg_per_cu(c->p, nbm)) / std::max(1, tp.wx));
+    const int64_t slots = int64_t(c->n_cu > 0 ? c->n_cu : 256) * wpc;
+    const int64_t columns = int64_t((tp.ntx + 1) / 2) * tp.nty; // of the larger colour
+    double best = 1e300;
+    for (int n = 1; n <= ncz; ++n) {
+      const int64_t rounds = (columns * n + slots - 1) / slots;
+      const double cost = double(rounds) * ((ncz + n - 1) / n + 1.0) * (1.0 + 1e-3 * n);
+      if (cost < best) { best = cost; ntc = n; }
     }
   }
-  tp.lz = lz;
-  tp.ntc = (ncz + lz - 1) / lz;
-  tp.zp = c->p * lz + 1;
+  tp.ntc = ntc;
+  tp.lz = (ncz + ntc - 1) / ntc; // longest chunk
+  tp.zp = c->p * tp.lz + 1;
 }
 
 // (Re)builds the per-quadrature-point metric of the general path.  The coefficients in force
@@ -503,7 +522,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         std::memset(&tp, 0, sizeof(tp));
         const int nbm = std::max(tj, ti);
         if (PR::geometry(c->p, nbm, tp) != 0) return STFEM_ERR_UNSUPPORTED;
-        plan_chunks(c, tp);
+        plan_chunks(c, tp, nbm);
         const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
         const size_t ntiles = size_t(tp.ntx) * tp.nty * tp.ntc;
         const size_t nyh = ntiles * nbm_r * tp.zp * tp.tX, nzh = ntiles * nbm_r * tp.tY * tp.tX,
@@ -525,8 +544,29 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         tp.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
         tp.stagger = getenv("STFEM_STAGGER") ? atoi(getenv("STFEM_STAGGER")) : 0;
         tp.stagger_div = getenv("STFEM_STAGGER_DIV") ? std::max(1, atoi(getenv("STFEM_STAGGER_DIV"))) : 256;
+        // diagnostic builds only (tools/build_abl.sh -DSTFEM_TIMELINE): phase timestamps of the
+        // even-colour launch, dumped to the file named by STFEM_TIMELINE after every apply
+        static long long *tl_dev = nullptr;
+        const char *tl_path = getenv("STFEM_TIMELINE");
+        const size_t tl_n = size_t(tp.ntx) * tp.nty * tp.ntc * 4 * tp.wx * tp.lz * 16;
+        if (tl_path) {
+          if (!tl_dev && hipMalloc(&tl_dev, tl_n * sizeof(long long)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+          HIP_TRY(hipMemsetAsync(tl_dev, 0, tl_n * sizeof(long long), st));
+          tp.timeline = tl_dev;
+        }
         rc = PR::tile(c->p, prm, tp, st);
         c->last_kernel = PR::tile_name();
+        if (tl_path && rc == 0) {
+          HIP_TRY(hipStreamSynchronize(st));
+          std::vector<long long> h(tl_n);
+          HIP_TRY(hipMemcpy(h.data(), tl_dev, tl_n * sizeof(long long), hipMemcpyDeviceToHost));
+          if (FILE *f = fopen(tl_path, "wb")) {
+            const long long hdr[4] = {(long long)tp.ntx * tp.nty * tp.ntc, 4 * tp.wx, tp.lz, 16};
+            fwrite(hdr, sizeof(long long), 4, f);
+            fwrite(h.data(), sizeof(long long), tl_n, f);
+            fclose(f);
+          }
+        }
       }
       if (rc == -3) return hip_fail(hipGetLastError(), "kernel launch");
       if (rc != 0) return STFEM_ERR_UNSUPPORTED;

@@ -74,9 +74,38 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
   real_t lxk = prm.fd_lx[0];
   STFEM_UNROLL
   for (int m = 1; m < N; ++m) lxk = k == m ? prm.fd_lx[m] : lxk;
+  // The diagonal factors aK (lx + ly + lz) + aM do not depend on the data; without these opaque
+  // copies the compiler computes all NBM x 25 of them once, outside the caller's layer loop, and
+  // keeps them in registers for the whole kernel.
+  real_t wK[NBM], wM[NBM];
+  STFEM_UNROLL
+  for (int i = 0; i < NBM; ++i) {
+    wK[i] = aK[i];
+    wM[i] = aM[i];
+    asm volatile("" : "+v"(wK[i]), "+v"(wM[i]));
+  }
+  asm volatile("" : "+v"(lxk));
   real_t R[N * N];
+  // the rows of the input blocks are read one row ahead of their use; the laundered pointer and
+  // the scheduling barrier keep the compiler from hoisting all rows' LDS reads to the top
+  // (NBM x 25 extra registers)
+  real_t vbuf[2][NBM][N];
+  auto load_row = [&](int y, real_t (&v)[NBM][N]) {
+    // (an opaque OFFSET: laundering the pointer itself would lose its LDS address space and turn
+    // the reads into flat loads, which also wait for every global store in flight)
+    int base = cell_in_wave * NBM * CBS + y * N + k;
+    asm volatile("" : "+v"(base));
+    STFEM_UNROLL
+    for (int i = 0; i < NBM; ++i)
+      if (i == 0 || i < prm.nbi) {
+        STFEM_UNROLL
+        for (int z = 0; z < N; ++z) v[i][z] = no_lds ? real_t(1) + z : lds[base + i * CBS + z * N * N];
+      }
+  };
+  load_row(0, vbuf[0]);
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
+    if (y + 1 < N) load_row(y + 1, vbuf[(y + 1) & 1]);
     const real_t sy = lxk + prm.fd_ly[y];
     real_t acc[N];
     if (NBM <= 2) {
@@ -84,14 +113,11 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
       STFEM_UNROLL
       for (int i = 0; i < NBM; ++i) {
         if (i == 0 || i < prm.nbi) {
-          const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
-          real_t v[N], t[N];
-          STFEM_UNROLL
-          for (int z = 0; z < N; ++z) v[z] = no_lds ? real_t(1) + z : in_lds[z * N * N + y * N + k];
-          fd_forward<N>(prm.fd_W, v, t);
+          real_t t[N];
+          fd_forward<N>(prm.fd_W, vbuf[y & 1][i], t);
           STFEM_UNROLL
           for (int z = 0; z < N; ++z) {
-            const real_t d = fma(aK[i], sy + prm.fd_lz[z], aM[i]);
+            const real_t d = fma(wK[i], sy + prm.fd_lz[z], wM[i]);
             acc[z] = i == 0 ? d * t[z] : fma(d, t[z], acc[z]);
           }
         }
@@ -104,12 +130,10 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
       STFEM_UNROLL
       for (int i = 0; i < NBM; ++i) {
         if (i < prm.nbi) {
-          const real_t *in_lds = lds + (cell_in_wave * NBM + i) * CBS;
           STFEM_UNROLL
           for (int z = 0; z < N; ++z) {
-            const real_t v = no_lds ? real_t(1) + z : in_lds[z * N * N + y * N + k];
-            ua[z] = fma(aK[i], v, ua[z]);
-            ub[z] = fma(aM[i], v, ub[z]);
+            ua[z] = fma(wK[i], vbuf[y & 1][i][z], ua[z]);
+            ub[z] = fma(wM[i], vbuf[y & 1][i][z], ub[z]);
           }
         }
       }
@@ -121,8 +145,10 @@ cell_core(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave, in
     }
     real_t r[N];
     fd_backward<N>(prm.fd_W, acc, r);
+    pin(r);
     STFEM_UNROLL
     for (int z = 0; z < N; ++z) R[y * N + z] = r[z];
+    __builtin_amdgcn_sched_barrier(0);
   }
   pin(R);
   wave_lds_fence();
@@ -248,12 +274,14 @@ cell_core_general(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
     if (y + 1 < N) {
-      const real_t *mp = met; // laundered: loads through it cannot be hoisted above this point
-      asm volatile("" : "+v"(mp));
+      // laundered offset: loads through it cannot be hoisted above this point (an offset, not the
+      // pointer, so that the loads stay global_load: flat loads would also count as LDS traffic)
+      int mo = 0;
+      asm volatile("" : "+v"(mo));
       STFEM_UNROLL
       for (int z = 0; z < N; ++z)
         STFEM_UNROLL
-      for (int c = 0; c < 8; ++c) mrow[(y + 1) & 1][z][c] = mp[(z * N * N + (y + 1) * N + k) * 8 + c];
+      for (int c = 0; c < 8; ++c) mrow[(y + 1) & 1][z][c] = met[mo + (z * N * N + (y + 1) * N + k) * 8 + c];
     }
     real_t ur[N], gzr[N], fz[N], t[N];
     STFEM_UNROLL

@@ -36,7 +36,8 @@ struct SweepParams {
 // a tile's upper y/z faces go to per-tile halo slabs and are added to their owner by a small
 // fix-up kernel.  No global atomics and no zeroing of dst are needed.
 struct TilePlan {
-  int cw, rows;      // cells per wave along x, waves (= cell rows along y) per tile
+  int cw, rows;      // cells per tile row (wx waves side by side), cell rows (one wave row each) per tile
+  int wx;            // waves per cell row: the workgroup has 64 * wx * rows threads
   int ntx, nty, ntc; // tiles in x, y and chunks in z
   int lz;            // cell layers per chunk (the last chunk may have fewer)
   int tX, tY, zp;    // slab extents: P*cw+1, P*rows+1, P*lz+1
@@ -48,6 +49,7 @@ struct TilePlan {
   int stagger_div;
   int experiment;    // ablation bit mask (STFEM_EXP; results are wrong when nonzero): 1 no src loads,
                      // 2 no cell core, 4 no LDS accumulation, 8 no store phase
+  long long *timeline; // diagnostic builds (-DSTFEM_TIMELINE): [block][wave][layer][16] timestamps
 };
 
 // Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.

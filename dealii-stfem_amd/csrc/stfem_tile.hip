@@ -36,19 +36,51 @@ namespace STFEM_PREC {
 
 namespace {
 
+// cells of one temporal block set a wave holds (the tile row must fit the 64 lanes of a store instruction)
+constexpr int tile_cells_per_wave(int p, int nbm)
+{
+  const int cpw = (64 / (p + 1)) / nbm;
+  return p * cpw + 1 > 64 ? 63 / p : cpw;
+}
+// Two ways to a tile row of two wave-widths, both measured no faster than the plain tile on cfg 1
+// (0.47 vs 0.47 ms; the 8-wave workgroup 0.51 ms) and therefore off by default:
+//   -DSTFEM_TILE_WIDE_WG  two waves side by side (8-wave workgroup, one per CU);
+//   -DSTFEM_TILE_SX2      every wave handles two cell groups one after the other (Cartesian path only).
+#if defined(STFEM_TILE_WIDE_WG)
+constexpr int tile_wx(int p, int nbm) { return p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64 ? 2 : 1; }
+constexpr int tile_sx(int, int) { return 1; }
+#elif defined(STFEM_TILE_SX2)
+constexpr int tile_wx(int, int) { return 1; }
+constexpr int tile_sx(int p, int nbm) { return p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64 ? 2 : 1; }
+#else
+constexpr int tile_wx(int, int) { return 1; }
+constexpr int tile_sx(int, int) { return 1; }
+#endif
+
+constexpr int tile_threads(int p, int nbm) { return 256 * tile_wx(p, nbm); }
+constexpr int tile_min_blocks(int p, int nbm, int minw) { return minw / tile_wx(p, nbm) > 0 ? minw / tile_wx(p, nbm) : 1; }
+
 template <int P, int NBM> struct TileGeom {
   using G = Geometry<P, NBM>;
   static constexpr int N = P + 1;
-  static constexpr int CW = G::CELLS_PER_WAVE;
-  static constexpr int ROWS = G::WAVES;
+  static constexpr int CWW = tile_cells_per_wave(P, NBM); // cells per wave
+  static constexpr int WX = tile_wx(P, NBM);              // waves per cell row
+  static constexpr int SX = tile_sx(P, NBM);              // cell groups a wave handles in turn
+  static constexpr int ROWS = 4;                           // cell rows (waves along y)
+  static constexpr int NWAVES = WX * ROWS;
+  static constexpr int NT = 64 * NWAVES;                   // threads per workgroup
+  static constexpr int CW = WX * SX * CWW;                 // cells per tile row
   static constexpr int TX = P * CW + 1;
+  static constexpr int LPR = TX <= 32 ? 32 : 64;           // store phase: lanes per slab row
+  static constexpr int RPI = 64 / LPR;                     // rows per wave-instruction
+  static constexpr int RPP = NWAVES * RPI;                 // rows per pass of the workgroup
   static constexpr int TY = P * ROWS + 1;
   static constexpr int PLANE = TX * TY;
   static constexpr int ACC = NBM * N * PLANE;              // accumulation slab (aliases trans)
-  static constexpr int TRANS = G::WAVES * G::LDS_PER_WAVE; // transpose slabs
+  static constexpr int TRANS = NWAVES * G::LDS_PER_WAVE;   // transpose slabs
   static constexpr int MAIN = ACC > TRANS ? ACC : TRANS;
   static constexpr int CARRY = NBM * PLANE;                // top plane carried between layers
-  static constexpr int CARRY_REGS = (CARRY + 255) / 256;   // ... in registers, CARRY_REGS per thread
+  static constexpr int CARRY_REGS = (CARRY + NT - 1) / NT; // ... in registers, CARRY_REGS per thread
   static constexpr int LDS_DOUBLES = MAIN;
 };
 
@@ -59,6 +91,9 @@ struct TileCoords {
   bool last_x, last_y, last_z;
 };
 
+// z-chunks are as equal as possible: chunk c covers cell layers [c*ncz/ntc, (c+1)*ncz/ntc)
+__device__ __forceinline__ int chunk_begin(int c, int ncz, int ntc) { return int(int64_t(c) * ncz / ntc); }
+
 __device__ __forceinline__ TileCoords tile_coords(const SweepParams &prm, const TilePlan &tp, int tx, int ty, int tc)
 {
   TileCoords t;
@@ -67,10 +102,10 @@ __device__ __forceinline__ TileCoords tile_coords(const SweepParams &prm, const 
   t.tc = tc;
   t.cx0 = t.tx * tp.cw;
   t.cy0 = t.ty * tp.rows;
-  t.cz0 = t.tc * tp.lz;
+  t.cz0 = chunk_begin(t.tc, prm.ncz, tp.ntc);
   t.ncx = min(tp.cw, prm.ncx - t.cx0);
   t.ncy = min(tp.rows, prm.ncy - t.cy0);
-  t.nlay = min(tp.lz, prm.ncz - t.cz0);
+  t.nlay = chunk_begin(t.tc + 1, prm.ncz, tp.ntc) - t.cz0;
   t.last_x = t.tx == tp.ntx - 1;
   t.last_y = t.ty == tp.nty - 1;
   t.last_z = t.tc == tp.ntc - 1;
@@ -120,9 +155,13 @@ __device__ __forceinline__ void load_plane_async(const real_t *s, int nx, real_t
       PA[y * N + x + 1] = v.y;
     }
     if (N & 1) {
+#ifdef STFEM_EXP_NO_TAIL_LOAD // timing experiment: one VMEM instruction less per row, same cache lines
+      PA[y * N + N - 1] = real_t(0);
+#else
       real_t v;
       asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(v) : "v"(row), "n"((N - 1) * 8) : "memory");
       PA[y * N + N - 1] = v;
+#endif
     }
   }
 #endif
@@ -146,12 +185,21 @@ __device__ __forceinline__ void wait_vmcnt(int n)
   else wait_vmcnt_imm<0>();
 }
 
+// dst rows are written once and not read again by this kernel
+#ifdef STFEM_NT_STORES
+#define STFEM_DST_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define STFEM_DST_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 template <int P, int NBM, int MINW, bool ADD, bool COEF, bool GEN, int COLOR>
-__global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
+__global__ __launch_bounds__(tile_threads(P, NBM), tile_min_blocks(P, NBM, MINW))
+void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 {
   using TG = TileGeom<P, NBM>;
   using G = Geometry<P, NBM>;
   constexpr int N = TG::N;
+  constexpr int NT = TG::NT, LPR = TG::LPR, RPI = TG::RPI, RPP = TG::RPP;
   constexpr int TX = TG::TX, TY = TG::TY, PLANE = TG::PLANE;
   __shared__ real_t smem[TG::LDS_DOUBLES];
   real_t *acc = smem; // [blk][k][Y][X], aliases the transpose slabs
@@ -169,17 +217,28 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     tile_coords(prm, tp, 2 * (id % ntxh) + COLOR, (id / ntxh) % tp.nty, id / (ntxh * tp.nty));
   const int tile_id = t.tx + tp.ntx * (t.ty + tp.nty * t.tc);
 
-  const bool lane_ok = lane < G::ACTIVE;
+  const bool lane_ok = lane < TG::CWW * NBM * N;
   const int l = lane_ok ? lane : 0;
   const int k = l % N;
   const int blk = (l / N) % NBM;
-  const int cxl = l / (N * NBM); // cell within the wave's row
-  const int cyl = wave;
-  const bool cell_ok = lane_ok && cxl < t.ncx && cyl < t.ncy;
-  const int cx = t.cx0 + (cell_ok ? cxl : 0), cy = t.cy0 + (cell_ok ? cyl : 0);
-  const bool in_active = cell_ok && blk < prm.nbi;
-  const bool out_active = cell_ok && blk < prm.nbo;
-  const int64_t cell_xy = cx + int64_t(prm.ncx) * cy;
+  constexpr int SX = TG::SX;
+  const int cxw = l / (N * NBM); // cell within the wave's group
+  const int cyl = wave / TG::WX;
+  // per cell group h of this wave
+  int cxl[SX], cx[SX];
+  bool cell_ok[SX], in_active[SX], out_active[SX], own_x_hi[SX];
+  int64_t cell_xy[SX];
+  const int cy = t.cy0 + ((lane_ok && cyl < t.ncy) ? cyl : 0);
+  STFEM_UNROLL
+  for (int h = 0; h < SX; ++h) {
+    cxl[h] = ((wave % TG::WX) * SX + h) * TG::CWW + cxw; // cell within the tile row
+    cell_ok[h] = lane_ok && cxl[h] < t.ncx && cyl < t.ncy;
+    cx[h] = t.cx0 + (cell_ok[h] ? cxl[h] : 0);
+    in_active[h] = cell_ok[h] && blk < prm.nbi;
+    out_active[h] = cell_ok[h] && blk < prm.nbo;
+    cell_xy[h] = cx[h] + int64_t(prm.ncx) * cy;
+    own_x_hi[h] = cxl[h] == t.ncx - 1; // last active cell of the row owns its x = P column
+  }
   const int64_t cells_per_layer = int64_t(prm.ncx) * prm.ncy;
 
   real_t aK0[NBM], aM0[NBM];
@@ -191,7 +250,6 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   }
 
   // which entries of this lane's result plane it initialises in the LDS slab ("owner")
-  const bool own_x_hi = cxl == t.ncx - 1; // last active cell of the row owns its x = P column
   const bool own_y_hi = cyl == t.ncy - 1;
 
   // Dirichlet rows only matter for tiles that touch the domain boundary (uniform test)
@@ -199,10 +257,14 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
                            ((prm.dmask & 4) && t.ty == 0) || ((prm.dmask & 8) && t.last_y);
 
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
-  const int64_t xy_base = int64_t(P) * cx + int64_t(prm.nx) * (int64_t(P) * cy);
   // lanes that feed nothing still load from a valid address; their planes are never used
-  const real_t *src_lane = prm.src[in_active ? blk : 0] + xy_base + plane_stride * k;
-  real_t *a = acc + ((blk * N + k) * TY + P * cyl) * TX + P * cxl;
+  const real_t *src_lane[SX];
+  int a_off[SX]; // this lane's result plane in the accumulation slab
+  STFEM_UNROLL
+  for (int h = 0; h < SX; ++h) {
+    src_lane[h] = prm.src[in_active[h] ? blk : 0] + int64_t(P) * cx[h] + int64_t(prm.nx) * (int64_t(P) * cy) + plane_stride * k;
+    a_off[h] = ((blk * N + k) * TY + P * cyl) * TX + P * cxl[h];
+  }
 
   const int xext = P * t.ncx, yext = P * t.ncy;
   const int ymax = t.last_y ? yext + 1 : yext; // rows [0, ymax) go to dst, row yext to yh otherwise
@@ -210,19 +272,20 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
   constexpr bool odd = COLOR == 1;
   const bool fast_tile = t.ncx == TG::CW && t.ncy == TG::ROWS && !t.last_y; // wave-uniform
   const bool collect_left = !odd && t.tx > 0, collect_right = !odd && !t.last_x;
-  constexpr int XE = (2 * NBM * N * TY + 255) / 256; // slab values per thread and layer
+  constexpr int XE = (2 * NBM * N * TY + NT - 1) / NT; // slab values per thread and layer
   const int nrows = prm.nbo * N * TY;
   const int64_t tile_goff = int64_t(P) * t.cx0 + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
                             plane_stride * (int64_t(P) * t.cz0);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-  // top plane of the previous layer: element tid + 256*m of [blk][Y][X] lives in this thread
+  // top plane of the previous layer: element tid + NT*m of [blk][Y][X] lives in this thread
   real_t carry[TG::CARRY_REGS];
   STFEM_UNROLL
   for (int m = 0; m < TG::CARRY_REGS; ++m) carry[m] = real_t(0);
 
-  real_t PA[N * N];
-  load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA);
+  real_t PA[SX][N * N];
+  STFEM_UNROLL
+  for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA[h]);
 #ifndef STFEM_F32
   wait_vmcnt_imm<0>();
 #endif
@@ -242,35 +305,40 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       for (int i = 0; i < tp.stagger; ++i) __builtin_amdgcn_s_sleep(16); // 16 x 64 cycles each
   }
 
+#ifdef STFEM_TIMELINE
+  // phase timestamps of the even-colour launch (constant 100 MHz clock, comparable across CUs);
+  // slot 15 of layer 0 holds HW_ID | XCC_ID << 32
+#define STFEM_TL(i)                                                                              \
+  do {                                                                                           \
+    if (COLOR == 0 && tp.timeline && lane == 0)                                                  \
+      tp.timeline[((int64_t(blockIdx.x) * TG::NWAVES + wave) * tp.lz + layer) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+  if (COLOR == 0 && tp.timeline && lane == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tp.timeline[((int64_t(blockIdx.x) * TG::NWAVES + wave) * tp.lz) * 16 + 15] = (long long)hw | ((long long)xcc << 32);
+  }
+#else
+#define STFEM_TL(i) do {} while (0)
+#endif
   real_t dummy = real_t(0);
   for (int layer = 0; layer < t.nlay; ++layer) {
+    STFEM_TL(0);
     const int cz = t.cz0 + layer;
     const bool last_layer = layer == t.nlay - 1;
     const bool z_boundary = ((prm.dmask & 16) && cz == 0) || ((prm.dmask & 32) && cz == prm.ncz - 1);
     const bool masked = xy_boundary || z_boundary;
-    PlaneMask pm = plane_mask<P>(prm, cx, cy, cz, k);
-    if (masked) {
-      STFEM_UNROLL
-      for (int y = 0; y < N; ++y)
+    PlaneMask pm[SX];
+    STFEM_UNROLL
+    for (int h = 0; h < SX; ++h) {
+      pm[h] = plane_mask<P>(prm, cx[h], cy, cz, k);
+      if (masked) {
         STFEM_UNROLL
-      for (int x = 0; x < N; ++x)
-        if (constrained<P>(pm, y, x)) PA[y * N + x] = real_t(0);
-    }
-    real_t aK[NBM], aM[NBM];
-    if (COEF) { // per-cell coefficients (operators.h:1060-1087) folded into the temporal weights
-      const int64_t c = cell_xy + cells_per_layer * cz;
-      const real_t fK = prm.coef_lap ? prm.coef_lap[c] : real_t(1);
-      const real_t fM = prm.coef_mass ? prm.coef_mass[c] : real_t(1);
-      STFEM_UNROLL
-      for (int i = 0; i < NBM; ++i) {
-        aK[i] = aK0[i] * fK;
-        aM[i] = aM0[i] * fM;
-      }
-    } else {
-      STFEM_UNROLL
-      for (int i = 0; i < NBM; ++i) {
-        aK[i] = aK0[i];
-        aM[i] = aM0[i];
+        for (int y = 0; y < N; ++y)
+          STFEM_UNROLL
+        for (int x = 0; x < N; ++x)
+          if (constrained<P>(pm[h], y, x)) PA[h][y * N + x] = real_t(0);
       }
     }
 
@@ -282,7 +350,7 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     // slab entry m of this thread: (side, row) -> LDS slab index or -1; evaluated twice (here for
     // the load, after the core for the add) rather than kept in registers across the core
     auto xe_slot = [&](int m, int &side, int &j, int &kk, int &Y) -> int {
-      const int e = tid + 256 * m;
+      const int e = tid + NT * m;
       side = e >= nrows ? 1 : 0;
       const int row = e - side * nrows;
       Y = row % TY;
@@ -305,11 +373,33 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       }
     }
 
-    if (GEN)
-      cell_core_general<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM,
-                                prm.metric + (cell_xy + cells_per_layer * cz) * (8 * N * N * N), PA);
-    else if (!(ex & 2))
-      cell_core<P, NBM>(prm, lds, cxl, blk, k, in_active, out_active, aK, aM, PA);
+    STFEM_TL(1);
+    STFEM_UNROLL
+    for (int h = 0; h < SX; ++h) {
+      real_t aK[NBM], aM[NBM];
+      if (COEF) { // per-cell coefficients (operators.h:1060-1087) folded into the temporal weights
+        const int64_t c = cell_xy[h] + cells_per_layer * cz;
+        const real_t fK = prm.coef_lap ? prm.coef_lap[c] : real_t(1);
+        const real_t fM = prm.coef_mass ? prm.coef_mass[c] : real_t(1);
+        STFEM_UNROLL
+        for (int i = 0; i < NBM; ++i) {
+          aK[i] = aK0[i] * fK;
+          aM[i] = aM0[i] * fM;
+        }
+      } else {
+        STFEM_UNROLL
+        for (int i = 0; i < NBM; ++i) {
+          aK[i] = aK0[i];
+          aM[i] = aM0[i];
+        }
+      }
+      if (GEN)
+        cell_core_general<P, NBM>(prm, lds, cxw, blk, k, in_active[h], out_active[h], aK, aM,
+                                  prm.metric + (cell_xy[h] + cells_per_layer * cz) * (8 * N * N * N), PA[h]);
+      else if (!(ex & 2))
+        cell_core<P, NBM>(prm, lds, cxw, blk, k, in_active[h], out_active[h], aK, aM, PA[h]);
+      if (SX > 1) pin(PA[h]); // finish this group before the next one starts
+    }
     // the slab values have long arrived; consuming them here on every path keeps the compiler
     // from draining the src prefetch (issued below) when their registers are recycled later
     STFEM_UNROLL
@@ -317,41 +407,53 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
 
     if (masked) {
       STFEM_UNROLL
+      for (int h = 0; h < SX; ++h)
+        STFEM_UNROLL
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
       for (int x = 0; x < N; ++x)
-        if (constrained<P>(pm, y, x)) PA[y * N + x] = real_t(0);
+        if (constrained<P>(pm[h], y, x)) PA[h][y * N + x] = real_t(0);
     }
 
+    STFEM_TL(2);
     STFEM_LAYER_BARRIER(); // all waves are done with the transpose slabs: the region becomes `acc`
+    STFEM_TL(3);
 
     // owner lanes initialise their DoFs
-    if (out_active && !(ex & 4)) {
-      STFEM_UNROLL
-      for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+    for (int h = 0; h < SX; ++h)
+      if (out_active[h] && !(ex & 4)) {
+        real_t *a = acc + a_off[h];
         STFEM_UNROLL
-      for (int x = 0; x < N; ++x) {
-        const bool owned = (x < P || own_x_hi) && (y < P || own_y_hi);
-        if (owned) a[y * TX + x] = PA[y * N + x];
+        for (int y = 0; y < N; ++y)
+          STFEM_UNROLL
+        for (int x = 0; x < N; ++x) {
+          const bool owned = (x < P || own_x_hi[h]) && (y < P || own_y_hi);
+          if (owned) a[y * TX + x] = PA[h][y * N + x];
+        }
       }
-    }
+    STFEM_TL(4);
     __syncthreads();
+    STFEM_TL(5);
     // the other sharers of a face / edge / vertex DoF add their part (ds_add_f64) ...
-    if (out_active && !(ex & 4)) {
-      STFEM_UNROLL
-      for (int y = 0; y < N; ++y)
+    STFEM_UNROLL
+    for (int h = 0; h < SX; ++h)
+      if (out_active[h] && !(ex & 4)) {
+        real_t *a = acc + a_off[h];
         STFEM_UNROLL
-      for (int x = 0; x < N; ++x) {
-        if (x < P && y < P) continue;
-        const bool owned = (x < P || own_x_hi) && (y < P || own_y_hi);
-        if (!owned) atomicAdd(&a[y * TX + x], PA[y * N + x]);
+        for (int y = 0; y < N; ++y)
+          STFEM_UNROLL
+        for (int x = 0; x < N; ++x) {
+          if (x < P && y < P) continue;
+          const bool owned = (x < P || own_x_hi[h]) && (y < P || own_y_hi);
+          if (!owned) atomicAdd(&a[y * TX + x], PA[h][y * N + x]);
+        }
       }
-    }
     // ... as do the plane carried over from the previous layer and the x-slab values
     if (layer > 0) {
       STFEM_UNROLL
       for (int m = 0; m < TG::CARRY_REGS; ++m) {
-        const int e = tid + 256 * m, j = e / PLANE;
+        const int e = tid + NT * m, j = e / PLANE;
         if (e < prm.nbo * PLANE) atomicAdd(&acc[j * (N - 1) * PLANE + e], carry[m]);
       }
     }
@@ -365,8 +467,13 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
     }
     // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
     // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
-    if (!last_layer && !(ex & 1)) load_plane_async<P>(src_lane + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA);
+    if (!last_layer && !(ex & 1)) {
+      STFEM_UNROLL
+      for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA[h]);
+    }
+    STFEM_TL(6);
     STFEM_LAYER_BARRIER();
+    STFEM_TL(7);
 
     // stream the finished planes to their destination: k = 0..P-1, and k = P on the last layer.
     // Fully unrolled with predicates: with loops here the compiler drains the prefetch loads
@@ -377,13 +484,13 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       // store phase is straight-line code: rows [0, P*ROWS) of every finished plane go to dst,
       // row P*ROWS to the y-halo slab.
       constexpr int XEXT = P * TG::CW, YMAX = P * TG::ROWS;
-      constexpr int NOF = (YMAX + 7) / 8;
+      constexpr int NOF = (YMAX + RPP - 1) / RPP;
       int lane_s = lane;
       asm volatile("" : "+v"(lane_s));
-      const int hw = 2 * wave_u + (lane_s >> 5), X = lane_s & 31;
+      const int hw = RPI * wave_u + lane_s / LPR, X = lane_s % LPR;
       const bool x_lane = X <= XEXT;
       const bool divert_lane = odd && (X == 0 || (X == XEXT && !t.last_x));
-      const unsigned lane_goff = X + prm.nx * (lane_s >> 5), lane_zoff = X + tp.tX * (lane_s >> 5);
+      const unsigned lane_goff = X + prm.nx * (lane_s / LPR), lane_zoff = X + tp.tX * (lane_s / LPR);
       const int lane_aoff = hw * TX + X;
       real_t *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
       STFEM_UNROLL
@@ -395,18 +502,18 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         STFEM_UNROLL
         for (int kk = 0; kk < N; ++kk)
           STFEM_UNROLL
-        for (int o = 0; o < NOF; ++o) sv[kk][o] = acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX];
-        real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u) + plane_stride * (int64_t(P) * layer);
+        for (int o = 0; o < NOF; ++o) sv[kk][o] = acc[(j * N + kk) * PLANE + lane_aoff + o * RPP * TX];
+        real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (RPI * wave_u) + plane_stride * (int64_t(P) * layer);
         const bool main_lane = x_lane && !(odd && divert_lane);
         if (main_lane) {
           STFEM_UNROLL
           for (int kk = 0; kk < P; ++kk)
             STFEM_UNROLL
           for (int o = 0; o < NOF; ++o) {
-            if ((YMAX % 8 != 0) && hw + 8 * o >= YMAX) continue;
-            real_t *d = dj + plane_stride * kk + int64_t(o * 8) * prm.nx + lane_goff;
+            if ((YMAX % RPP != 0) && hw + RPP * o >= YMAX) continue;
+            real_t *d = dj + plane_stride * kk + int64_t(o * RPP) * prm.nx + lane_goff;
             if (ADD) *d += sv[kk][o];
-            else *d = sv[kk][o];
+            else STFEM_DST_STORE(d, sv[kk][o]);
           }
         }
         if (odd && divert_lane) { // the two shared columns of an odd tile go to its x-slabs
@@ -415,31 +522,31 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
           for (int kk = 0; kk < P; ++kk)
             STFEM_UNROLL
           for (int o = 0; o < NOF; ++o) {
-            const int Y = hw + 8 * o;
-            if ((YMAX % 8 == 0) || Y < YMAX) xs[kk * tp.tY + Y] = sv[kk][o];
+            const int Y = hw + RPP * o;
+            if ((YMAX % RPP == 0) || Y < YMAX) xs[kk * tp.tY + Y] = sv[kk][o];
           }
         }
         if (last_layer) { // the top plane leaves too: to the z-halo slab, or to dst on the last chunk
-          real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+          real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (RPI * wave_u);
           real_t *xs = xslab_out + (j * tp.zp + P * layer) * tp.tY;
           STFEM_UNROLL
           for (int o = 0; o < NOF; ++o) {
-            const int Y = hw + 8 * o;
-            const bool row_ok = (YMAX % 8 == 0) || Y < YMAX;
+            const int Y = hw + RPP * o;
+            const bool row_ok = (YMAX % RPP == 0) || Y < YMAX;
             if (row_ok && x_lane) {
-              real_t *d = dj + plane_stride * P + int64_t(o * 8) * prm.nx + lane_goff;
-              if (!t.last_z) (zj + o * 8 * tp.tX)[lane_zoff] = sv[P][o];
+              real_t *d = dj + plane_stride * P + int64_t(o * RPP) * prm.nx + lane_goff;
+              if (!t.last_z) (zj + o * RPP * tp.tX)[lane_zoff] = sv[P][o];
               else if (odd && divert_lane) xs[P * tp.tY + Y] = sv[P][o];
               else if (ADD) *d += sv[P][o];
-              else *d = sv[P][o];
+              else STFEM_DST_STORE(d, sv[P][o]);
             }
           }
         }
       }
       // row Y = P*ROWS of every finished plane: to the y-halo slab (the tile is not last in y)
       STFEM_UNROLL
-      for (int o = 0; o < (NBM * N + 7) / 8; ++o) {
-        const int r = hw + 8 * o;
+      for (int o = 0; o < (NBM * N + RPP - 1) / RPP; ++o) {
+        const int r = hw + RPP * o;
         const int j = r / kend, kk = r - j * kend;
         if (r < prm.nbo * kend && x_lane)
           tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + P * layer + kk) * tp.tX + X] =
@@ -447,17 +554,17 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
       }
     } else
     if (!(ex & 8)) {
-      constexpr int NO = (TY + 7) / 8; // rows per half-wave and plane
+      constexpr int NO = (TY + RPP - 1) / RPP; // row passes per plane
       // store-phase lane roles: one slab row per half-wave (32 lanes, X = lane within the half).
       // Derived from a laundered lane id so that they are recomputed here instead of being kept
       // in ~15 VGPRs across the register-critical core.
       int lane_s = lane;
       asm volatile("" : "+v"(lane_s));
-      const int hw = 2 * wave_u + (lane_s >> 5), X = lane_s & 31;
+      const int hw = RPI * wave_u + lane_s / LPR, X = lane_s % LPR;
       const bool x_lane = X <= xext;
       const bool divert_lane = odd && (X == 0 || (X == xext && !t.last_x));
       real_t *const xslab_out = (X == 0 ? tp.xl : tp.xr) + int64_t(tile_id) * NBM * tp.zp * tp.tY;
-      const unsigned lane_goff = X + prm.nx * (lane_s >> 5), lane_zoff = X + tp.tX * (lane_s >> 5);
+      const unsigned lane_goff = X + prm.nx * (lane_s / LPR), lane_zoff = X + tp.tX * (lane_s / LPR);
       const int lane_aoff = hw * TX + X;
       STFEM_UNROLL
       for (int j = 0; j < NBM; ++j) {
@@ -470,9 +577,9 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         for (int kk = 0; kk < N; ++kk)
           STFEM_UNROLL
         for (int o = 0; o < NO; ++o)
-          sv[kk][o] = (kk < kend && hw + 8 * o < ymax && x_lane && !(ex & 32)) ? acc[(j * N + kk) * PLANE + lane_aoff + o * 8 * TX] : real_t(0);
-        real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (2 * wave_u); // wave-uniform
-        real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (2 * wave_u);
+          sv[kk][o] = (kk < kend && hw + RPP * o < ymax && x_lane && !(ex & 32)) ? acc[(j * N + kk) * PLANE + lane_aoff + o * RPP * TX] : real_t(0);
+        real_t *dj = prm.dst[j] + tile_goff + int64_t(prm.nx) * (RPI * wave_u); // wave-uniform
+        real_t *zj = tp.zh + (int64_t(tile_id) * NBM + j) * tp.tY * tp.tX + tp.tX * (RPI * wave_u);
         STFEM_UNROLL
         for (int kk = 0; kk < N; ++kk) {
           if (kk >= kend) continue;
@@ -481,22 +588,22 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
           real_t *xs = xslab_out + (j * tp.zp + zl) * tp.tY;
           STFEM_UNROLL
           for (int o = 0; o < NO; ++o) {
-            const int Y = hw + 8 * o;
+            const int Y = hw + RPP * o;
             if (ex & 64) { dummy += sv[kk][o]; continue; }
             if (Y < ymax && x_lane) {
               const real_t v = sv[kk][o];
-              if (to_zh) (zj + o * 8 * tp.tX)[lane_zoff] = v;
+              if (to_zh) (zj + o * RPP * tp.tX)[lane_zoff] = v;
               else if (divert_lane) xs[Y] = v;
-              else if (ADD) (dj + plane_stride * zl + int64_t(o * 8) * prm.nx)[lane_goff] += v;
-              else (dj + plane_stride * zl + int64_t(o * 8) * prm.nx)[lane_goff] = v;
+              else if (ADD) (dj + plane_stride * zl + int64_t(o * RPP) * prm.nx)[lane_goff] += v;
+              else STFEM_DST_STORE(&(dj + plane_stride * zl + int64_t(o * RPP) * prm.nx)[lane_goff], v);
             }
           }
         }
       }
       if (!t.last_y && !(ex & 128)) { // row Y = yext of every finished plane: to the y-halo slab
         STFEM_UNROLL
-        for (int o = 0; o < (NBM * N + 7) / 8; ++o) {
-          const int r = hw + 8 * o;
+        for (int o = 0; o < (NBM * N + RPP - 1) / RPP; ++o) {
+          const int r = hw + RPP * o;
           const int j = r / kend, kk = r - j * kend;
           if (r < prm.nbo * kend && x_lane)
             tp.yh[((int64_t(tile_id) * NBM + j) * tp.zp + P * layer + kk) * tp.tX + X] =
@@ -504,27 +611,31 @@ __global__ __launch_bounds__(256, MINW) void st_sweep_cart_tile(const SweepParam
         }
       }
     }
+    STFEM_TL(8);
     if (!last_layer) { // top plane: carried to the next layer
       STFEM_UNROLL
       for (int m = 0; m < TG::CARRY_REGS; ++m) {
-        const int e = tid + 256 * m, j = e / PLANE;
+        const int e = tid + NT * m, j = e / PLANE;
         if (e < prm.nbo * PLANE) carry[m] = acc[(j * (N - 1) + P) * PLANE + e];
       }
     }
+    STFEM_TL(9);
     STFEM_LAYER_BARRIER(); // slab free again for the next layer's transposes
+    STFEM_TL(10);
     // the prefetched planes must have landed before PA is touched; the stores issued after
     // them may stay in flight.  Lower bound of the stores this wave has issued since: one per
     // (block, plane, row group) whose first half-wave row exists.
     {
       int n_o = 0;
       STFEM_UNROLL
-      for (int o = 0; o < (TY + 7) / 8; ++o) n_o += (2 * wave_u + 8 * o < ymax) ? 1 : 0;
+      for (int o = 0; o < (TY + RPP - 1) / RPP; ++o) n_o += (RPI * wave_u + RPP * o < ymax) ? 1 : 0;
 #ifndef STFEM_F32
       wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
 #else
       (void)n_o;
 #endif
     }
+    STFEM_TL(11);
   }
 #ifdef STFEM_ABLATION
   if (dummy == real_t(1.2345e30)) tp.zh[0] = dummy; // experiment sink, never true
@@ -544,7 +655,8 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
   // owned local extents
   const int Xn = P * t.ncx + (t.last_x ? 1 : 0), Yn = P * t.ncy + (t.last_y ? 1 : 0),
             Zn = P * t.nlay + (t.last_z ? 1 : 0);
-  const int X = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int lpr = tp.tX <= 32 ? 32 : 64, nrg = 256 / lpr; // lanes per row, rows per pass
+  const int X = threadIdx.x % lpr, rg = threadIdx.x / lpr;
   if (X >= Xn) return;
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
   const int64_t g0 = int64_t(P) * t.cx0 + X + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
@@ -552,6 +664,8 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
   const int dxn = (X == 0) ? has_x : 0; // the x = 0 column also collects from the tiles at tx - 1
   const int XpL = P * tp.cw;            // that column in the left neighbour's coordinates
   const int tid_y = id - tp.ntx, tid_z = id - tp.ntx * tp.nty, tid_yz = tid_z - tp.ntx;
+  // top plane of the chunk below, in its own slab coordinates
+  const int top_below = has_z ? P * (t.cz0 - chunk_begin(t.tc - 1, prm.ncz, tp.ntc)) : 0;
   for (int j = 0; j < prm.nbo; ++j) {
     real_t *d = prm.dst[j] + g0;
     const int64_t sy = tp.zp * tp.tX, sz = tp.tY * tp.tX;
@@ -561,18 +675,18 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
     // the same slabs of the tiles at tx - 1 (one tile earlier in the numbering)
     const int64_t left_y = int64_t(nbm) * sy, left_z = int64_t(nbm) * sz;
     if (has_y) // rows Y = 0, Z >= (has_z ? 1 : 0): contributions of the tiles below in y
-      for (int Z = rg + has_z; Z < Zn; Z += 8) {
+      for (int Z = rg + has_z; Z < Zn; Z += nrg) {
         real_t s = yh_y[Z * tp.tX + X];
         if (dxn) s += (yh_y - left_y)[Z * tp.tX + XpL];
         d[plane_stride * Z] += s;
       }
     if (has_z) // plane Z = 0: tiles below in z, and for its row Y = 0 also below in y
-      for (int Y = rg; Y < Yn; Y += 8) {
+      for (int Y = rg; Y < Yn; Y += nrg) {
         real_t s = zh_z[Y * tp.tX + X];
         if (dxn) s += (zh_z - left_z)[Y * tp.tX + XpL];
         if (Y == 0 && has_y) {
-          s += yh_y[X] + yh_yz[P * tp.lz * tp.tX + X];
-          if (dxn) s += (yh_y - left_y)[XpL] + (yh_yz - left_y)[P * tp.lz * tp.tX + XpL];
+          s += yh_y[X] + yh_yz[top_below * tp.tX + X];
+          if (dxn) s += (yh_y - left_y)[XpL] + (yh_yz - left_y)[top_below * tp.tX + XpL];
         }
         d[int64_t(prm.nx) * Y] += s;
       }
@@ -592,9 +706,9 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
 #define STFEM_LAUNCH(WW, AA, CC, GG)                                                                        \
   do {                                                                                                     \
     if (colour == 1)                                                                                       \
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 1>), dim3(nblocks), dim3(256), 0, st, prm, tp); \
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 1>), dim3(nblocks), dim3(TileGeom<P, NBM>::NT), 0, st, prm, tp); \
     else                                                                                                   \
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 0>), dim3(nblocks), dim3(256), 0, st, prm, tp); \
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 0>), dim3(nblocks), dim3(TileGeom<P, NBM>::NT), 0, st, prm, tp); \
   } while (0)
     if (prm.metric) { // general geometry / per-q coefficients (baked into the metric)
       if (tp.add) STFEM_LAUNCH(1, true, false, true);
@@ -619,8 +733,7 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
   // half the registers and half the LDS per workgroup: twice the waves per SIMD
   return launch_tile_w<P, NBM, 4>(prm, tp, st);
 #else
-  static const int minw = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 2;
-  return minw == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
+  return tile_wg_per_cu(P, NBM) == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
 #endif
 }
 
@@ -709,9 +822,9 @@ int tile_geometry(int p, int nbm, TilePlan &plan)
   const int n = p + 1;
   const int cb = 64 / n;
   if (nbm > cb) return -2;
-  plan.cw = cb / nbm;
-  // the store phase maps one slab row to 32 lanes
-  if (p * plan.cw + 1 > 32) plan.cw = 31 / p;
+  // the store phase maps one slab row to at most 64 lanes
+  plan.wx = tile_wx(p, nbm);
+  plan.cw = plan.wx * tile_sx(p, nbm) * tile_cells_per_wave(p, nbm);
   plan.rows = 4;
   plan.tX = p * plan.cw + 1;
   plan.tY = p * plan.rows + 1;
@@ -731,7 +844,11 @@ int STFEM_PASTE(launch_cart_tile_p, STFEM_TILE_P)(const SweepParams &prm, const 
   const int nbm = round_nbm(prm.nbi > prm.nbo ? prm.nbi : prm.nbo);
 #define STFEM_CASE(NB) \
   if (nbm == NB) return launch_tile_t<STFEM_TILE_P, NB>(prm, plan, st);
+#ifdef STFEM_QUICK // development builds: only the two-block instantiation
+  STFEM_CASE(2)
+#else
   STFEM_CASE(1) STFEM_CASE(2) STFEM_CASE(3) STFEM_CASE(4) STFEM_CASE(6) STFEM_CASE(8)
+#endif
 #undef STFEM_CASE
   return -2;
 }

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Phase timeline of the tile kernel (diagnostic build: tools/build_abl.sh -DSTFEM_TIMELINE, run with
+STFEM_LIB=.../libstfem_abl.so STFEM_TIMELINE=<file>).  Prints mean phase durations per layer and
+how the workgroups sharing a CU overlap."""
+import sys
+import numpy as np
+
+NAMES = ["0-1 mask/coef/xslab-load issue", "1-2 cell core", "2-3 barrier A", "3-4 owner init",
+         "4-5 barrier B", "5-6 adds + src prefetch issue", "6-7 barrier C", "7-8 store phase",
+         "8-9 carry read", "9-10 barrier D", "10-11 wait src prefetch"]
+
+raw = np.fromfile(sys.argv[1], dtype=np.int64)
+nblk, nw, lz, ns = raw[:4]
+t = raw[4:].reshape(nblk, nw, lz, ns)
+used = t[:, 0, 0, 0] > 0
+t = t[used]
+print(f"{t.shape[0]} recorded workgroups x {nw} waves x {lz} layers; tick = 10 ns")
+d = np.diff(t[..., :12], axis=-1).astype(float) / 100.0  # us
+tot = (t[..., 11] - t[..., 0]) / 100.0
+print(f"layer time (0->11): mean {tot.mean():.2f} us, median {np.median(tot):.2f}, p90 {np.percentile(tot, 90):.2f}")
+for i, n in enumerate(NAMES):
+    print(f"  {n:36s} mean {d[..., i].mean():6.2f} us  median {np.median(d[..., i]):6.2f}  p90 {np.percentile(d[..., i], 90):6.2f}")
+wg_start, wg_end = t[:, :, 0, 0].min(1), t[:, :, -1, 11].max(1)
+print(f"workgroup lifetime mean {(wg_end - wg_start).mean() / 100:.1f} us; kernel span {(wg_end.max() - wg_start.min()) / 100:.1f} us")
+# which CU: HW_ID cu_id[11:8] sh_id[12] se_id[15:13] (gfx9 layout), XCC_ID low bits
+hw = t[:, 0, 0, 15]
+cu = ((hw >> 32) & 0xF) * 4096 + (hw & 0xFF00)
+ids, counts = np.unique(cu, return_counts=True)
+print(f"distinct (xcc, se, sh, cu) keys: {len(ids)}; workgroups per key: min {counts.min()} max {counts.max()}")
+# concurrency: at the start of each workgroup, how many others on the same key are alive
+conc = []
+for key in ids[:64]:
+    m = cu == key
+    s, e = wg_start[m], wg_end[m]
+    for i in range(len(s)):
+        conc.append(int(((s <= s[i]) & (e > s[i])).sum()))
+print("workgroups alive on the same CU at a workgroup's start (incl. itself): mean %.2f" % np.mean(conc))
+# phase overlap of co-resident pairs: fraction of time both are inside the cell core
+key = ids[0]
+m = np.where(cu == key)[0]
+print("first CU: workgroup start/end (us rel.):", [(round((wg_start[i] - wg_start[m].min()) / 100, 1), round((wg_end[i] - wg_start[m].min()) / 100, 1)) for i in m])
