@@ -14,8 +14,8 @@ _LIB = os.path.join(_HERE, "libstfem_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "stfem_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("stfem_oracle.c", "stfem_oracle_stokes.c", "stfem_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libstfem_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB
@@ -58,6 +58,12 @@ def lib():
         L.stfo_time_weights.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]
         L.stfo_time_weights_wave.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int,
                                              _dp, _dp, _dp, _dp, _dp]
+        L.stfo_stokes_n_velocity.restype = C.c_long
+        L.stfo_stokes_n_velocity.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.stfo_stokes_n_pressure.restype = C.c_long
+        L.stfo_stokes_n_pressure.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.stfo_stokes_apply.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
         _lib = L
     return _lib
 
@@ -195,3 +201,60 @@ class Oracle:
         A = np.zeros((self.n_dofs, self.n_dofs))
         lib().stfo_dense(self._h, mass, laplace, _p(A))
         return A
+
+
+# ---- Stokes two-field operator (stfem_oracle_stokes.c)
+
+def stokes_block_index(nt, it, v, d, n_variables=2, variable_major=True):
+    """BlockSlice::index (reference include/fe_time.h:956-967)"""
+    if variable_major:
+        return it * (n_variables * nt) + v * nt + d
+    return it * (n_variables * nt) + d * n_variables + v
+
+
+class StokesOracle:
+    """StokesMatrixFreeOperator (cell loop) + vector mass + SystemMatrixStokes::vmult, restated in
+    the reference's structure (operators.h:825-867: K.vmult, scatter with Alpha, M.vmult, scatter
+    with Beta, one source time dof after the other)."""
+
+    def __init__(self, ncell, vertices, dirichlet_mask, viscosity, pu=2):
+        self.nc = (C.c_int * 3)(*ncell)
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1)
+        self.mask, self.nu, self.pu = int(dirichlet_mask), float(viscosity), pu
+        self.n_u = lib().stfo_stokes_n_velocity(self.nc, pu)
+        self.n_p = lib().stfo_stokes_n_pressure(self.nc, pu)
+
+    def apply(self, U, P, wK=1.0, wM=0.0):
+        U = np.ascontiguousarray(U, dtype=np.float64).reshape(3 * self.n_u)
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(self.n_p)
+        ou = np.zeros(3 * self.n_u); op = np.zeros(self.n_p)
+        rc = lib().stfo_stokes_apply(self.nc, _p(self.vertices), self.pu, self.mask, self.nu, wK, wM,
+                                     _p(U), _p(P), _p(ou), _p(op), 0)
+        assert rc == 0
+        return ou.reshape(3, self.n_u), op
+
+    def st_vmult(self, Alpha, Beta, n_timesteps, n_timedofs, blocks, variable_major=True):
+        """blocks: list of arrays in BlockSlice order (velocity blocks 3*n_u, pressure n_p)."""
+        nt = n_timedofs
+        idx = lambda it, v, d: stokes_block_index(nt, it, v, d, 2, variable_major)  # noqa: E731
+        eps10 = 10 * np.finfo(np.float64).eps
+        dst = [np.zeros_like(np.asarray(b, dtype=np.float64).reshape(-1)) for b in blocks]
+        for it in range(n_timesteps):
+            for d in range(nt):
+                u = np.asarray(blocks[idx(it, 0, d)]).reshape(3, self.n_u)
+                p = np.asarray(blocks[idx(it, 1, d)]).reshape(self.n_p)
+                tu, tp = self.apply(u, p, 1.0, 0.0)          # K.vmult(tmp, tmp_src)
+                i = idx(it, 0, d)
+                for jt in range(n_timesteps):
+                    for jd in range(nt):
+                        for jv, t in ((0, tu.reshape(-1)), (1, tp)):
+                            j = idx(jt, jv, jd)
+                            if abs(Alpha[j, i]) > eps10:      # internal::scatter, operators.h:91-110
+                                dst[j] += Alpha[j, i] * t
+                mu, _ = self.apply(u, np.zeros(self.n_p), 0.0, 1.0)  # M.vmult(tmp.block(0), ...)
+                for jt in range(n_timesteps):
+                    for jd in range(nt):
+                        j = idx(jt, 0, jd)
+                        if abs(Beta[j, i]) > eps10:
+                            dst[j] += Beta[j, i] * mu.reshape(-1)
+        return dst

@@ -80,6 +80,16 @@ int stfo_time_weights(int type, int r, double tau, int nsteps, double *Alpha, do
 int stfo_time_weights_wave(int type, int r, double tau, int nsteps, double *Alpha_lhs,
                            double *Beta_lhs, double *rhs_uK, double *rhs_uM, double *rhs_vM);
 
+/* ---- Stokes two-field cell operator (stfem_oracle_stokes.c; operators.h:1501-1575, cell loop
+ * only).  Velocity FE_Q(pu)^3 as 3 component arrays (component-major) of the scalar numbering,
+ * pressure FE_Q(pu-1); homogeneous Dirichlet (mask as above) on the velocity only.
+ *   out_u (+)= wK * (nu K u - B^T p) + wM * M u ;   out_p (+)= wK * (div u, q)          */
+long stfo_stokes_n_velocity(const int ncell[3], int pu); /* per component */
+long stfo_stokes_n_pressure(const int ncell[3], int pu);
+int stfo_stokes_apply(const int ncell[3], const double *vertices, int pu, int dirichlet_mask,
+                      double nu, double wK, double wM, const double *u, const double *p,
+                      double *out_u, double *out_p, int add);
+
 #ifdef __cplusplus
 }
 #endif

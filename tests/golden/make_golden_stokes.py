@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Golden fixtures of the Stokes two-field operator, from FIRST PRINCIPLES:
+dense numpy assembly with full 3D shape-function tables, independent of oracle/*.c and of the
+HIP library.
+
+  spatial:    out_u = nu K u - B^T p,  out_p = B u           (reference include/operators.h:1525-1575:
+              pressure.submit_value(div u); velocity.submit_gradient(nu grad u - p I))
+  space-time: SystemMatrixStokes::vmult (operators.h:696-700, 825-867): for every source time dof i
+              dst[j, v] += Alpha(j_v, i_0) * (K_S (u_i, p_i))_v ;  dst[j, 0] += Beta(j_0, i_0) * M u_i
+              with Alpha, Beta laid out as get_fe_time_weights_stokes does (fe_time.h:1242-1285)
+              and blocks numbered by BlockSlice (fe_time.h:956-967), variable-major.
+
+Velocity FE_Q(2)^3, pressure FE_Q(1), QGauss(3), MappingQ1; homogeneous Dirichlet on the velocity.
+Layout: velocity block = 3 component arrays (component-major) of the scalar Q2 numbering.
+
+Run:  python tests/golden/make_golden_stokes.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import (gauss01, gll01_np, lagrange_table, structured_vertices,  # noqa: E402
+                         time_weights_single)
+
+
+def tables3d(p, xq):
+    V, G = lagrange_table(gll01_np(p + 1), xq)
+    nq, n1 = len(xq), p + 1
+    N = np.einsum("zc,yb,xa->zyxcba", V, V, V).reshape(nq ** 3, n1 ** 3)
+    dN = np.stack([
+        np.einsum("zc,yb,xa->zyxcba", V, V, G).reshape(nq ** 3, n1 ** 3),
+        np.einsum("zc,yb,xa->zyxcba", V, G, V).reshape(nq ** 3, n1 ** 3),
+        np.einsum("zc,yb,xa->zyxcba", G, V, V).reshape(nq ** 3, n1 ** 3)], axis=1)
+    return N, dN
+
+
+def dense_stokes(pu, ncell, vertices, mask):
+    pp = pu - 1
+    nq = pu + 1
+    xq, wq = gauss01(nq)
+    Nu_, dNu = tables3d(pu, xq)
+    Np_, _ = tables3d(pp, xq)
+    W = np.einsum("z,y,x->zyx", wq, wq, wq).reshape(-1)
+    QX = np.tile(xq, nq * nq); QY = np.tile(np.repeat(xq, nq), nq); QZ = np.repeat(xq, nq * nq)
+    ndu = [pu * n + 1 for n in ncell]
+    ndp = [pp * n + 1 for n in ncell]
+    NU, NP = int(np.prod(ndu)), int(np.prod(ndp))
+    K = np.zeros((NU, NU)); M = np.zeros((NU, NU)); B = np.zeros((3, NP, NU))
+    nvx, nvy = ncell[0] + 1, ncell[1] + 1
+    verts = vertices.reshape(-1, 3)
+    for cz in range(ncell[2]):
+        for cy in range(ncell[1]):
+            for cx in range(ncell[0]):
+                X = np.array([verts[(cx + i) + nvx * ((cy + j) + nvy * (cz + k))]
+                              for k in range(2) for j in range(2) for i in range(2)])
+                fx = np.stack([1 - QX, QX], 1); fy = np.stack([1 - QY, QY], 1); fz = np.stack([1 - QZ, QZ], 1)
+                dd = np.array([-1.0, 1.0])
+                J = np.zeros((nq ** 3, 3, 3))
+                for k in range(2):
+                    for j in range(2):
+                        for i in range(2):
+                            Xv = X[i + 2 * j + 4 * k]
+                            J[:, :, 0] += np.outer(dd[i] * fy[:, j] * fz[:, k], Xv)
+                            J[:, :, 1] += np.outer(fx[:, i] * dd[j] * fz[:, k], Xv)
+                            J[:, :, 2] += np.outer(fx[:, i] * fy[:, j] * dd[k], Xv)
+                det = np.linalg.det(J)
+                Jinv = np.linalg.inv(J)
+                g = np.einsum("qed,qea->qda", Jinv, dNu)
+                Ke = np.einsum("q,qda,qdb->ab", W * det, g, g)
+                Me = np.einsum("q,qa,qb->ab", W * det, Nu_, Nu_)
+                Be = np.einsum("q,qb,qda->dba", W * det, Np_, g)
+                iu = np.array([(pu * cx + a) + ndu[0] * ((pu * cy + b) + ndu[1] * (pu * cz + c))
+                               for c in range(pu + 1) for b in range(pu + 1) for a in range(pu + 1)])
+                ip = np.array([(pp * cx + a) + ndp[0] * ((pp * cy + b) + ndp[1] * (pp * cz + c))
+                               for c in range(pp + 1) for b in range(pp + 1) for a in range(pp + 1)])
+                K[np.ix_(iu, iu)] += Ke
+                M[np.ix_(iu, iu)] += Me
+                for d in range(3):
+                    B[d][np.ix_(ip, iu)] += Be[d]
+    con = np.zeros(ndu[::-1], dtype=bool)
+    if mask & 1: con[:, :, 0] = True
+    if mask & 2: con[:, :, -1] = True
+    if mask & 4: con[:, 0, :] = True
+    if mask & 8: con[:, -1, :] = True
+    if mask & 16: con[0, :, :] = True
+    if mask & 32: con[-1, :, :] = True
+    con = con.reshape(-1)
+    K[con, :] = 0; K[:, con] = 0; M[con, :] = 0; M[:, con] = 0
+    B[:, :, con] = 0
+    return K, M, B
+
+
+def stokes_apply(K, M, B, nu, U, P):
+    """U [3, NU], P [NP] -> (nu K u - B^T p, B u, M u)"""
+    ou = np.stack([nu * K @ U[c] - B[c].T @ P for c in range(3)])
+    op = sum(B[c] @ U[c] for c in range(3))
+    mu = np.stack([M @ U[c] for c in range(3)])
+    return ou, op, mu
+
+
+def block_index(nt, nv, it, v, d):  # BlockSlice, variable-major (fe_time.h:956-967)
+    return it * (nv * nt) + v * nt + d
+
+
+def main():
+    cases = [
+        # name, ncell, lower, upper, jitter, mask, nu, time kind, r, tau
+        ("stokes_cart_2x2x2", (2, 2, 2), (0, 0, 0), (1, 1.5, 0.7), 0.0, 63, 1.0, "cg", 2, 0.1),
+        ("stokes_pert_2x3x2", (2, 3, 2), (0, 0, 0), (1, 1, 1), 0.15, 63, 0.05, "dg", 1, 1 / 16),
+        ("stokes_free_3x2x2", (3, 2, 2), (-1, -1, -1), (1, 1, 1), 0.1, 0b010011, 2.5, "cg", 1, 0.25),
+    ]
+    for (name, ncell, lo, up, jit, mask, nu, kind, r, tau) in cases:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        verts = structured_vertices(ncell, lo, up, jit, seed=23)
+        K, M, B = dense_stokes(2, ncell, verts, mask)
+        NU, NP = K.shape[0], B.shape[1]
+        At, Bt = time_weights_single(kind, r, tau)  # single step: nt x nt
+        nt = At.shape[0]
+        # get_fe_time_weights_stokes layout (one time step at once): 2 nt x 2 nt
+        nb = 2 * nt
+        Alpha = np.zeros((nb, nb)); Beta = np.zeros((nb, nb))
+        for iv in range(2):
+            for jv in range(2):
+                if not (iv == 1 and jv == 1):
+                    for a in range(nt):
+                        for b in range(nt):
+                            Alpha[block_index(nt, 2, 0, iv, a), block_index(nt, 2, 0, jv, b)] = At[a, b]
+        for a in range(nt):
+            for b in range(nt):
+                Beta[block_index(nt, 2, 0, 0, a), block_index(nt, 2, 0, 0, b)] = Bt[a, b]
+        U = rng.uniform(-1, 1, size=(nt, 3, NU)); P = rng.uniform(-1, 1, size=(nt, NP))
+        DU = np.zeros((nt, 3, NU)); DP = np.zeros((nt, NP))
+        SU = np.zeros((nt, 3, NU)); SP = np.zeros((nt, NP)); MU = np.zeros((nt, 3, NU))
+        for i in range(nt):
+            ou, op, mu = stokes_apply(K, M, B, nu, U[i], P[i])
+            SU[i], SP[i], MU[i] = ou, op, mu
+            col = block_index(nt, 2, 0, 0, i)
+            for j in range(nt):
+                DU[j] += Alpha[block_index(nt, 2, 0, 0, j), col] * ou + Beta[block_index(nt, 2, 0, 0, j), col] * mu
+                DP[j] += Alpha[block_index(nt, 2, 0, 1, j), col] * op
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), ncell=np.array(ncell), vertices=verts,
+                            mask=mask, nu=nu, nt=nt, Alpha=Alpha, Beta=Beta, U=U, P=P, DU=DU, DP=DP,
+                            SU=SU, SP=SP, MU=MU)
+        print(name, "NU", NU, "NP", NP, "nt", nt, "|K|", np.abs(K).max(), "|B|", np.abs(B).max(),
+              "B*1", np.abs(sum(B[c] @ np.ones(NU) for c in range(3))).max() if mask == 0 else "-")
+
+
+if __name__ == "__main__":
+    main()

@@ -39,3 +39,25 @@ print("workgroups alive on the same CU at a workgroup's start (incl. itself): me
 key = ids[0]
 m = np.where(cu == key)[0]
 print("first CU: workgroup start/end (us rel.):", [(round((wg_start[i] - wg_start[m].min()) / 100, 1), round((wg_end[i] - wg_start[m].min()) / 100, 1)) for i in m])
+
+# do the workgroups march in lockstep?  fraction of live workgroups (wave 0) inside the cell core /
+# inside a memory-issuing phase, sampled every microsecond
+t0 = t[:, 0, :, :12]
+lo, hi = t0[..., 0].min(), t0[..., 11].max()
+ticks = np.arange(lo, hi, 100)
+core = np.zeros(len(ticks)); mem = np.zeros(len(ticks)); alive = np.zeros(len(ticks))
+for w in range(t0.shape[0]):
+    for l in range(t0.shape[1]):
+        s = t0[w, l]
+        if s[0] == 0:
+            continue
+        a = np.searchsorted(ticks, [s[0], s[11], s[1], s[2], s[5], s[6], s[7], s[8]])
+        alive[a[0]:a[1]] += 1
+        core[a[2]:a[3]] += 1
+        mem[a[4]:a[5]] += 1
+        mem[a[6]:a[7]] += 1
+ok = alive > 0.5 * alive.max()
+fc, fm = core[ok] / alive[ok], mem[ok] / alive[ok]
+print(f"fraction of live workgroups in the core: mean {fc.mean():.2f} min {fc.min():.2f} max {fc.max():.2f} std {fc.std():.3f}")
+print(f"fraction in gather-issue / store phases: mean {fm.mean():.2f} min {fm.min():.2f} max {fm.max():.2f} std {fm.std():.3f}")
+print("core fraction per us (first 60):", " ".join(f"{x:.2f}" for x in fc[:60]))
