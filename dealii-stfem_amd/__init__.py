@@ -85,6 +85,19 @@ SIGNATURES = {
     "stfem_coefficient_per_cell": (C.c_int, [C.POINTER(C.c_int32), _dp, C.c_double, C.c_double,
                                              C.c_double, C.c_double, C.POINTER(C.c_int32), _dp,
                                              _dp, _dp]),
+    "stfem_stokes_create": (C.c_int, [C.POINTER(_MeshDesc), C.c_int, C.c_double, C.POINTER(_vp)]),
+    "stfem_stokes_destroy": (None, [_vp]),
+    "stfem_stokes_n_velocity_dofs": (C.c_int64, [_vp]),
+    "stfem_stokes_n_pressure_dofs": (C.c_int64, [_vp]),
+    "stfem_stokes_vector_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "stfem_stokes_vector_destroy": (None, [_vp, _vp]),
+    "stfem_stokes_vector_upload": (C.c_int, [_vp, C.c_int, _vp, _dp]),
+    "stfem_stokes_vector_download": (C.c_int, [_vp, C.c_int, _vp, _dp]),
+    "stfem_stokes_vmult": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "stfem_stokes_mass_vmult": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "stfem_stokes_st_vmult": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.POINTER(_vp),
+                                        C.POINTER(_vp), _vp]),
+    "stfem_stokes_last_hip_error": (C.c_char_p, []),
     "stfem_strerror": (C.c_char_p, [C.c_int]),
     "stfem_last_hip_error": (C.c_char_p, []),
     "stfem_last_kernel_name": (C.c_char_p, [_vp]),
@@ -326,3 +339,115 @@ def dot(ctx, a, b, n_own=0, stream=None):
     out = C.c_double(0.0)
     _check(lib().stfem_dot(ctx._h, a._h, b._h, n_own, C.byref(out), stream), "stfem_dot")
     return out.value
+
+
+# ------------------------------------------------------------------------------- Stokes (8a-14)
+
+def stokes_block_index(n_timedofs, timestep, variable, timedof, variable_major=True):
+    """BlockSlice::index (reference include/fe_time.h:956-967), two variables."""
+    if variable_major:
+        return timestep * (2 * n_timedofs) + variable * n_timedofs + timedof
+    return timestep * (2 * n_timedofs) + timedof * 2 + variable
+
+
+def get_fe_time_weights_stokes(type_, r, time_step_size, n_timesteps_at_once=1):
+    """Alpha, Beta of get_fe_time_weights_stokes (fe_time.h:1242-1285): the scalar matrices of
+    get_fe_time_weights scattered into the (variable, time dof) block structure; the
+    pressure-pressure block of Alpha stays empty, Beta only couples velocity with velocity."""
+    A, B, _, _ = get_fe_time_weights(type_, r, time_step_size, n_timesteps_at_once)
+    n = A.shape[0]
+    nt = n // n_timesteps_at_once
+    Alpha = np.zeros((2 * n, 2 * n)); Beta = np.zeros((2 * n, 2 * n))
+    idx = lambda v, k: stokes_block_index(nt, k // nt, v, k % nt)  # noqa: E731
+    for a in range(n):
+        for b in range(n):
+            for iv in range(2):
+                for jv in range(2):
+                    if not (iv == 1 and jv == 1):
+                        Alpha[idx(iv, a), idx(jv, b)] = A[a, b]
+            Beta[idx(0, a), idx(0, b)] = B[a, b]
+    return Alpha, Beta
+
+
+class StokesMatrixFreeOperator:
+    """StokesMatrixFreeOperator + SystemMatrixStokes of the reference (include/operators.h:1193-1575,
+    666-868) for the cell loop, FE_Q(2)^3 x FE_Q(1).  Vectors are device pointers (e.g.
+    torch.Tensor.data_ptr()): velocity 3 * n_velocity doubles (component-major), pressure n_pressure."""
+
+    def __init__(self, ncell, vertices=None, lower=(0, 0, 0), upper=(1, 1, 1), dirichlet_mask=63,
+                 viscosity=1.0, velocity_degree=2, device=0):
+        m = _MeshDesc()
+        self.ncell = tuple(int(v) for v in ncell)
+        m.ncell[:] = self.ncell
+        self._verts = None
+        if vertices is not None:
+            self._verts = np.ascontiguousarray(vertices, dtype=np.float64)
+            m.vertices = _p(self._verts)
+        m.lower[:] = lower
+        m.upper[:] = upper
+        m.dirichlet_mask = dirichlet_mask
+        m.device = device
+        h = _vp()
+        _check(lib().stfem_stokes_create(C.byref(m), velocity_degree, viscosity, C.byref(h)),
+               "stfem_stokes_create")
+        self._h = h
+        self.n_velocity = lib().stfem_stokes_n_velocity_dofs(h)
+        self.n_pressure = lib().stfem_stokes_n_pressure_dofs(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.stfem_stokes_destroy(self._h)
+            self._h = None
+
+    def initialize_dof_vector(self, variable, host=None):
+        """Device vector of `variable` (0 velocity, 1 pressure) as a StokesVector; optionally filled."""
+        return StokesVector(self, variable, host)
+
+    def vmult(self, dst_u, dst_p, src_u, src_p, stream=None):
+        dst_u, dst_p, src_u, src_p = (getattr(v, "ptr", v) for v in (dst_u, dst_p, src_u, src_p))
+        _check(lib().stfem_stokes_vmult(self._h, dst_u, dst_p, src_u, src_p, stream), "stfem_stokes_vmult")
+
+    def mass_vmult(self, dst_u, src_u, stream=None):
+        dst_u, src_u = getattr(dst_u, "ptr", dst_u), getattr(src_u, "ptr", src_u)
+        _check(lib().stfem_stokes_mass_vmult(self._h, dst_u, src_u, stream), "stfem_stokes_mass_vmult")
+
+    def st_vmult(self, Alpha, Beta, n_timesteps_at_once, n_timedofs, dst_blocks, src_blocks,
+                 variable_major=True, stream=None):
+        """SystemMatrixStokes::vmult; dst_blocks / src_blocks: device pointers in BlockSlice order."""
+        nb = 2 * n_timesteps_at_once * n_timedofs
+        A = np.ascontiguousarray(Alpha, dtype=np.float64); B = np.ascontiguousarray(Beta, dtype=np.float64)
+        assert A.shape == (nb, nb) and B.shape == (nb, nb) and len(dst_blocks) == nb and len(src_blocks) == nb
+        d = (_vp * nb)(*[getattr(v, "ptr", v) for v in dst_blocks])
+        s_ = (_vp * nb)(*[getattr(v, "ptr", v) for v in src_blocks])
+        _check(lib().stfem_stokes_st_vmult(self._h, n_timesteps_at_once, n_timedofs, int(variable_major),
+                                           _p(A), _p(B), d, s_, stream), "stfem_stokes_st_vmult")
+
+
+class StokesVector:
+    """One device vector of a StokesMatrixFreeOperator (velocity: 3 * n_velocity, pressure: n_pressure)."""
+
+    def __init__(self, op, variable, host=None):
+        self.op, self.variable = op, variable
+        self.size = 3 * op.n_velocity if variable == 0 else op.n_pressure
+        h = _vp()
+        _check(lib().stfem_stokes_vector_create(op._h, variable, C.byref(h)), "stfem_stokes_vector_create")
+        self.ptr = h.value
+        if host is not None:
+            self.upload(host)
+
+    def upload(self, host):
+        a = np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
+        assert a.size == self.size
+        _check(lib().stfem_stokes_vector_upload(self.op._h, self.variable, self.ptr, _p(a)), "stfem_stokes_vector_upload")
+        return self
+
+    def download(self):
+        out = np.zeros(self.size)
+        _check(lib().stfem_stokes_vector_download(self.op._h, self.variable, self.ptr, _p(out)),
+               "stfem_stokes_vector_download")
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _lib is not None and getattr(self.op, "_h", None):
+            _lib.stfem_stokes_vector_destroy(self.op._h, self.ptr)
+            self.ptr = None

@@ -163,6 +163,49 @@ int stfem_coefficient_per_cell(const int32_t ncell[3], const double *vertices, d
                                double c3, double distort_coeff, const int32_t subdivisions[3],
                                const double lower[3], const double upper[3], double *out);
 
+/* ---- Stokes two-field operator (BASELINE configs[4]; cell loop only: LoopType::Cell,
+ * include/operators.h:1228-1229, i.e. no weak boundary ids and delta0 = 0; the Nitsche / outflow /
+ * CIP face terms of operators.h:1577-1751 are not built).  Velocity FE_Q(2)^3, pressure FE_Q(1),
+ * QGauss(3), MappingQ1 on the mesh of `mesh`; mesh->dirichlet_mask constrains the velocity
+ * (homogeneous), the pressure is unconstrained.  fp64.
+ * Layout: a velocity vector is 3 * n_velocity_dofs doubles, component-major, every component in
+ * the scalar FE_Q(2) numbering of this header; a pressure vector is n_pressure_dofs doubles in
+ * the scalar FE_Q(1) numbering.  All vector arguments are DEVICE pointers. */
+typedef struct stfem_stokes_ctx stfem_stokes_ctx; /* replaces MatrixFree + StokesMatrixFreeOperator state */
+/* StokesMatrixFreeOperator ctor (operators.h:1200-1251); only velocity_degree == 2 is built */
+int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double viscosity,
+                        stfem_stokes_ctx **out);
+void stfem_stokes_destroy(stfem_stokes_ctx *ctx);
+int64_t stfem_stokes_n_velocity_dofs(const stfem_stokes_ctx *ctx); /* per component */
+int64_t stfem_stokes_n_pressure_dofs(const stfem_stokes_ctx *ctx);
+/* StokesMatrixFreeOperator::initialize_dof_vector(vec, variable) (operators.h:1254-1275):
+ * variable 0 = velocity (3 * n_velocity_dofs doubles), 1 = pressure; zero-initialised device
+ * memory.  upload / download copy a whole vector from / to the host and are synchronous. */
+int stfem_stokes_vector_create(stfem_stokes_ctx *ctx, int variable, double **device_out);
+void stfem_stokes_vector_destroy(stfem_stokes_ctx *ctx, double *device_vec);
+int stfem_stokes_vector_upload(stfem_stokes_ctx *ctx, int variable, double *device_vec, const double *host);
+int stfem_stokes_vector_download(stfem_stokes_ctx *ctx, int variable, const double *device_vec, double *host);
+/* StokesMatrixFreeOperator::vmult (operators.h:1501-1575, OperatorMode::none):
+ *   dst_u = nu K u - B^T p,   dst_p = B u      (B u = (div u, q)) */
+int stfem_stokes_vmult(stfem_stokes_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                       const double *src_p, void *stream);
+/* the MassMatrixType of SystemMatrixStokes (vector mass, operators.h:1013-1018 with
+ * n_components = dim): dst_u = M u */
+int stfem_stokes_mass_vmult(stfem_stokes_ctx *ctx, double *dst_u, const double *src_u, void *stream);
+/* SystemMatrixStokes::vmult (operators.h:696-700, 825-867): blocks are numbered by
+ * BlockSlice::index(timestep, variable, timedof) (fe_time.h:956-967; variable 0 = velocity,
+ * 1 = pressure), Alpha/Beta are the host row-major (2*nt*ns)^2 matrices of
+ * get_fe_time_weights_stokes (fe_time.h:1242-1285).  For every source time dof (it, id):
+ *   dst[index(jt,v,jd)] += Alpha(index(jt,v,jd), index(it,0,id)) * (K_S (u,p))_v
+ *   dst[index(jt,0,jd)] += Beta (index(jt,0,jd), index(it,0,id)) * M u
+ * entries with |.| <= 10 eps are skipped as in internal::scatter (operators.h:91-110); dst is
+ * zeroed first.  One fused launch per source time dof.  The reference's Tvmult for this class
+ * (operators.h:702-745) indexes dst by the source time dof and is not a transpose; it is not built. */
+int stfem_stokes_st_vmult(stfem_stokes_ctx *ctx, int n_timesteps_at_once, int n_timedofs,
+                          int variable_major, const double *Alpha, const double *Beta,
+                          double *const *dst_blocks, const double *const *src_blocks, void *stream);
+const char *stfem_stokes_last_hip_error(void);
+
 const char *stfem_strerror(int status);
 /* text of the last failing HIP call on this thread ("" if none) */
 const char *stfem_last_hip_error(void);

@@ -1,0 +1,103 @@
+"""GPU parity of the Stokes two-field operator through the C-ABI
+(stfem_stokes_*): against the dense numpy fixtures and against the CPU oracle on a larger seeded
+mesh.  Tolerance rel-L2 <= 1e-12 (fp64)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FIXTURES = ["stokes_cart_2x2x2", "stokes_pert_2x3x2", "stokes_free_3x2x2"]
+
+
+def rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def stfem():
+    mod = importlib.import_module("dealii-stfem_amd")
+    mod.lib()
+    return mod
+
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_stokes_golden_fixture(name, stfem):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    op = stfem.StokesMatrixFreeOperator(tuple(g["ncell"]), vertices=g["vertices"], dirichlet_mask=int(g["mask"]),
+                                        viscosity=float(g["nu"]))
+    nt = int(g["nt"])
+    assert op.n_velocity == g["U"].shape[2] and op.n_pressure == g["P"].shape[1]
+    for i in range(nt):
+        u, p = op.initialize_dof_vector(0, g["U"][i]), op.initialize_dof_vector(1, g["P"][i])
+        ou = op.initialize_dof_vector(0, np.full(3 * op.n_velocity, 7.0))   # vmult overwrites
+        opr = op.initialize_dof_vector(1, np.full(op.n_pressure, -3.0))
+        op.vmult(ou, opr, u, p)
+        mu = op.initialize_dof_vector(0, np.full(3 * op.n_velocity, 5.0))
+        op.mass_vmult(mu, u)
+        assert rel(ou.download(), g["SU"][i]) < TOL
+        assert rel(opr.download(), g["SP"][i]) < TOL
+        assert rel(mu.download(), g["MU"][i]) < TOL
+    # space-time: SystemMatrixStokes::vmult
+    src = [None] * (2 * nt); dst = [None] * (2 * nt)
+    for d in range(nt):
+        src[stfem.stokes_block_index(nt, 0, 0, d)] = op.initialize_dof_vector(0, g["U"][d])
+        src[stfem.stokes_block_index(nt, 0, 1, d)] = op.initialize_dof_vector(1, g["P"][d])
+    for j in range(2 * nt):
+        dst[j] = op.initialize_dof_vector(src[j].variable, np.full(src[j].size, 11.0))
+    op.st_vmult(g["Alpha"], g["Beta"], 1, nt, dst, src)
+    for d in range(nt):
+        assert rel(dst[stfem.stokes_block_index(nt, 0, 0, d)].download(), g["DU"][d]) < TOL
+        assert rel(dst[stfem.stokes_block_index(nt, 0, 1, d)].download(), g["DP"][d]) < TOL
+
+
+@pytest.mark.parametrize("variable_major", [True, False])
+def test_stokes_vs_oracle_two_steps(variable_major, stfem):
+    """cG(2), two time steps at once (4 time dofs, 8 blocks), perturbed 5x4x6 mesh, against the
+    reference-structured CPU oracle; both BlockSlice orderings."""
+    from oracle import oracle
+    nc = (5, 4, 6)
+    verts = stfem.mesh_vertices(nc, distort=0.15, seed=77)
+    nu, mask = 0.3, 0b111011
+    op = stfem.StokesMatrixFreeOperator(nc, vertices=verts, dirichlet_mask=mask, viscosity=nu)
+    orc = oracle.StokesOracle(nc, verts, mask, nu)
+    assert (op.n_velocity, op.n_pressure) == (orc.n_u, orc.n_p)
+    ns, r = 2, 2
+    Alpha_vm, Beta_vm = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 16, ns)
+    nt = r
+    nb = 2 * nt * ns
+    # permute to the requested block ordering
+    perm = np.zeros(nb, dtype=int)
+    for it in range(ns):
+        for v in range(2):
+            for d in range(nt):
+                perm[stfem.stokes_block_index(nt, it, v, d, variable_major)] = stfem.stokes_block_index(nt, it, v, d, True)
+    Alpha, Beta = Alpha_vm[np.ix_(perm, perm)], Beta_vm[np.ix_(perm, perm)]
+    rng = np.random.default_rng(5)
+    blocks = [None] * nb
+    for it in range(ns):
+        for d in range(nt):
+            blocks[stfem.stokes_block_index(nt, it, 0, d, variable_major)] = rng.uniform(-1, 1, 3 * orc.n_u)
+            blocks[stfem.stokes_block_index(nt, it, 1, d, variable_major)] = rng.uniform(-1, 1, orc.n_p)
+    ref = orc.st_vmult(Alpha, Beta, ns, nt, blocks, variable_major)
+    var = [0 if b.size == 3 * orc.n_u else 1 for b in blocks]
+    src = [op.initialize_dof_vector(v, b) for v, b in zip(var, blocks)]
+    dst = [op.initialize_dof_vector(v) for v in var]
+    op.st_vmult(Alpha, Beta, ns, nt, dst, src, variable_major)
+    for j in range(nb):
+        assert rel(dst[j].download(), ref[j]) < TOL, j
+
+
+def test_stokes_errors(stfem):
+    op = stfem.StokesMatrixFreeOperator((2, 2, 2))
+    u, p = op.initialize_dof_vector(0), op.initialize_dof_vector(1)
+    with pytest.raises(stfem.StfemError) as e:
+        op.vmult(u, p, u, p)
+    assert e.value.status == -6  # STFEM_ERR_ALIAS, as deal.II forbids vmult(dst, src) with dst == src
+    with pytest.raises(stfem.StfemError) as e:
+        stfem.StokesMatrixFreeOperator((2, 2, 2), velocity_degree=3)
+    assert e.value.status == -2  # STFEM_ERR_UNSUPPORTED

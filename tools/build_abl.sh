@@ -9,5 +9,5 @@ FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract
 /opt/rocm/bin/hipcc $FL -DSTFEM_TILE_P=4 -c -o build_abl/stfem_tile_p4.o stfem_tile.hip &
 /opt/rocm/bin/hipcc $FL -c -o build_abl/stfem_tile.o stfem_tile.hip &
 wait
-OBJS="host_tables.o stfem_kernels.o stfem_kernels_f32.o build_abl/stfem_tile.o stfem_tile_p1.o stfem_tile_p2.o stfem_tile_p3.o build_abl/stfem_tile_p4.o stfem_tile_f32.o stfem_tile_f32_p1.o stfem_tile_f32_p2.o stfem_tile_f32_p3.o stfem_tile_f32_p4.o stfem_capi.o"
+OBJS="host_tables.o stfem_kernels.o stfem_kernels_f32.o build_abl/stfem_tile.o stfem_tile_p1.o stfem_tile_p2.o stfem_tile_p3.o build_abl/stfem_tile_p4.o stfem_tile_f32.o stfem_tile_f32_p1.o stfem_tile_f32_p2.o stfem_tile_f32_p3.o stfem_tile_f32_p4.o stfem_capi.o stfem_stokes.o"
 /opt/rocm/bin/hipcc -shared -fPIC -o ../libstfem_abl.so $OBJS
