@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
 {
   constexpr int CELL_LDS = 81 + 8 + 27 * 13; // u[3][27], p[8], per point: Fref[9], dq, mu[3]
   __shared__ double smem[8 * CELL_LDS];
+  __shared__ double tS[9], tD[9], tP[6]; // 1D tables [q*3+a], [q*3+a], [q*2+a]
+  if (threadIdx.x < 9) { tS[threadIdx.x] = prm.Su[threadIdx.x]; tD[threadIdx.x] = prm.Du[threadIdx.x]; }
+  if (threadIdx.x < 6) tP[threadIdx.x] = prm.Sp[threadIdx.x];
   const int slot = threadIdx.x >> 5, t = threadIdx.x & 31;
   const long long ncells = (long long)prm.ncx * prm.ncy * prm.ncz;
   const long long cell = (long long)blockIdx.x * 8 + slot;
@@ -120,27 +123,22 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
     JxW = det * prm.wq[a] * prm.wq[b] * prm.wq[c];
 
-    // 1D table rows of this point
-    double sx[3], sy[3], sz[3], dx[3], dy[3], dz[3];
+    // the node loops stay rolled (small code, few registers); 1D table rows come from LDS
+    double sx[3], dx[3];
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-      sx[n] = a == 0 ? prm.Su[n] : (a == 1 ? prm.Su[3 + n] : prm.Su[6 + n]);
-      sy[n] = b == 0 ? prm.Su[n] : (b == 1 ? prm.Su[3 + n] : prm.Su[6 + n]);
-      sz[n] = c == 0 ? prm.Su[n] : (c == 1 ? prm.Su[3 + n] : prm.Su[6 + n]);
-      dx[n] = a == 0 ? prm.Du[n] : (a == 1 ? prm.Du[3 + n] : prm.Du[6 + n]);
-      dy[n] = b == 0 ? prm.Du[n] : (b == 1 ? prm.Du[3 + n] : prm.Du[6 + n]);
-      dz[n] = c == 0 ? prm.Du[n] : (c == 1 ? prm.Du[3 + n] : prm.Du[6 + n]);
-    }
+    for (int n = 0; n < 3; ++n) { sx[n] = tS[a * 3 + n]; dx[n] = tD[a * 3 + n]; }
     double gref[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, uval[3] = {0, 0, 0};
-#pragma unroll
-    for (int nc = 0; nc < 3; ++nc)
-#pragma unroll
-      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll 1
+    for (int nc = 0; nc < 3; ++nc) {
+      const double sz = tS[c * 3 + nc], dz = tD[c * 3 + nc];
+#pragma unroll 1
+      for (int nb = 0; nb < 3; ++nb) {
+        const double sy = tS[b * 3 + nb], dy = tD[b * 3 + nb];
+        const double syz = sy * sz, dyz = dy * sz, sdz = sy * dz;
 #pragma unroll
         for (int na = 0; na < 3; ++na) {
           const int n = na + 3 * (nb + 3 * nc);
-          const double gx = dx[na] * sy[nb] * sz[nc], gy = sx[na] * dy[nb] * sz[nc], gz = sx[na] * sy[nb] * dz[nc],
-                       val = sx[na] * sy[nb] * sz[nc];
+          const double gx = dx[na] * syz, gy = sx[na] * dyz, gz = sx[na] * sdz, val = sx[na] * syz;
 #pragma unroll
           for (int comp = 0; comp < 3; ++comp) {
             const double w = ul[comp * 27 + n];
@@ -150,18 +148,16 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
             uval[comp] = fma(w, val, uval[comp]);
           }
         }
+      }
+    }
     double pval = 0.0;
 #pragma unroll
     for (int nc = 0; nc < 2; ++nc)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int na = 0; na < 2; ++na) {
-          const double px = a == 0 ? prm.Sp[na] : (a == 1 ? prm.Sp[2 + na] : prm.Sp[4 + na]);
-          const double py = b == 0 ? prm.Sp[nb] : (b == 1 ? prm.Sp[2 + nb] : prm.Sp[4 + nb]);
-          const double pz = c == 0 ? prm.Sp[nc] : (c == 1 ? prm.Sp[2 + nc] : prm.Sp[4 + nc]);
-          pval = fma(pl[na + 2 * (nb + 2 * nc)], px * py * pz, pval);
-        }
+        for (int na = 0; na < 2; ++na)
+          pval = fma(pl[na + 2 * (nb + 2 * nc)], tP[a * 2 + na] * tP[b * 2 + nb] * tP[c * 2 + nc], pval);
     double grad[3][3];
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp)
@@ -186,34 +182,28 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   // ---- integrate (this lane = velocity node (a, b, c); lanes 0..7 also pressure node)
   double rK[3] = {0, 0, 0}, rM[3] = {0, 0, 0}, rP = 0.0;
   if (active) {
-#pragma unroll
-    for (int qc = 0; qc < 3; ++qc)
-#pragma unroll
-      for (int qb = 0; qb < 3; ++qb)
+#pragma unroll 1
+    for (int qc = 0; qc < 3; ++qc) {
+      const double szv = tS[qc * 3 + c], dzv = tD[qc * 3 + c], pz = tP[qc * 2 + pc];
+#pragma unroll 1
+      for (int qb = 0; qb < 3; ++qb) {
+        const double syv = tS[qb * 3 + b], dyv = tD[qb * 3 + b], py = tP[qb * 2 + pb];
+        const double syz = syv * szv, dyz = dyv * szv, sdz = syv * dzv;
 #pragma unroll
         for (int qa = 0; qa < 3; ++qa) {
           const int q = qa + 3 * (qb + 3 * qc);
-          // S[q*3 + node], node = this lane's (a, b, c)
-          const double sxv = a == 0 ? prm.Su[qa * 3] : (a == 1 ? prm.Su[qa * 3 + 1] : prm.Su[qa * 3 + 2]);
-          const double syv = b == 0 ? prm.Su[qb * 3] : (b == 1 ? prm.Su[qb * 3 + 1] : prm.Su[qb * 3 + 2]);
-          const double szv = c == 0 ? prm.Su[qc * 3] : (c == 1 ? prm.Su[qc * 3 + 1] : prm.Su[qc * 3 + 2]);
-          const double dxv = a == 0 ? prm.Du[qa * 3] : (a == 1 ? prm.Du[qa * 3 + 1] : prm.Du[qa * 3 + 2]);
-          const double dyv = b == 0 ? prm.Du[qb * 3] : (b == 1 ? prm.Du[qb * 3 + 1] : prm.Du[qb * 3 + 2]);
-          const double dzv = c == 0 ? prm.Du[qc * 3] : (c == 1 ? prm.Du[qc * 3 + 1] : prm.Du[qc * 3 + 2]);
-          const double gx = dxv * syv * szv, gy = sxv * dyv * szv, gz = sxv * syv * dzv, val = sxv * syv * szv;
+          const double sxv = tS[qa * 3 + a], dxv = tD[qa * 3 + a];
+          const double gx = dxv * syz, gy = sxv * dyz, gz = sxv * sdz, val = sxv * syz;
           const double *f = fl + q * 13;
 #pragma unroll
           for (int comp = 0; comp < 3; ++comp) {
             rK[comp] = fma(gx, f[comp * 3], fma(gy, f[comp * 3 + 1], fma(gz, f[comp * 3 + 2], rK[comp])));
             rM[comp] = fma(val, f[10 + comp], rM[comp]);
           }
-          if (t < 8) {
-            const double px = pa == 0 ? prm.Sp[qa * 2] : prm.Sp[qa * 2 + 1];
-            const double py = pb == 0 ? prm.Sp[qb * 2] : prm.Sp[qb * 2 + 1];
-            const double pz = pc == 0 ? prm.Sp[qc * 2] : prm.Sp[qc * 2 + 1];
-            rP = fma(px * py * pz, f[9], rP);
-          }
+          if (t < 8) rP = fma(tP[qa * 2 + pa] * py * pz, f[9], rP);
         }
+      }
+    }
     // ---- distribute_local_to_global (constrained velocity rows are not written)
     for (int j = 0; j < prm.nout; ++j) {
       if (!con && prm.out_u[j]) {
