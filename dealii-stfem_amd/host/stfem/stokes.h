@@ -1,0 +1,184 @@
+// Host-side mirror of the reference's Stokes operators (include/operators.h:666-868
+// SystemMatrixStokes, 1193-1575 StokesMatrixFreeOperator; include/fe_time.h:901-1221 BlockSlice,
+// 1242-1285 get_fe_time_weights_stokes) on the C-ABI (stfem_stokes_*), cell loop only.
+#pragma once
+#include "fe_time.h"
+#include "operators.h"
+
+#include <array>
+
+namespace stfem {
+
+// fe_time.h:901-1010 block_indexing / BlockSlice: block <-> (timestep, variable, timedof)
+class BlockSlice {
+public:
+  BlockSlice(unsigned n_timesteps_at_once, unsigned n_variables, unsigned n_timedofs, bool variable_major = true)
+    : nts_(n_timesteps_at_once), nv_(n_variables), ntd_(n_timedofs), variable_major_(variable_major)
+  {}
+  unsigned index(unsigned timestep, unsigned variable, unsigned timedof) const
+  {
+    return variable_major_ ? timestep * (nv_ * ntd_) + variable * ntd_ + timedof
+                           : timestep * (nv_ * ntd_) + timedof * nv_ + variable;
+  }
+  std::array<unsigned, 3> decompose(unsigned i) const
+  {
+    const unsigned ts = i / (nv_ * ntd_), r = i % (nv_ * ntd_);
+    return variable_major_ ? std::array<unsigned, 3>{{ts, r / ntd_, r % ntd_}}
+                           : std::array<unsigned, 3>{{ts, r % nv_, r / nv_}};
+  }
+  unsigned n_timesteps_at_once() const { return nts_; }
+  unsigned n_variables() const { return nv_; }
+  unsigned n_timedofs() const { return ntd_; }
+  unsigned n_blocks() const { return nts_ * nv_ * ntd_; }
+  bool variable_major() const { return variable_major_; }
+
+private:
+  unsigned nts_, nv_, ntd_;
+  bool variable_major_;
+};
+
+// fe_time.h:1242-1285: {Alpha, Beta} in the (variable, time dof) block structure (the rhs
+// matrices Gamma, Zeta of the reference's return value are not needed by vmult)
+template <typename Number>
+std::array<FullMatrix<Number>, 2> get_fe_time_weights_stokes(TimeStepType type, unsigned r, double time_step_size,
+                                                             unsigned n_timesteps_at_once = 1)
+{
+  const auto tw = get_fe_time_weights<Number>(type, r, time_step_size, n_timesteps_at_once);
+  const unsigned n = tw[0].m(), nt = n / n_timesteps_at_once;
+  BlockSlice s(n_timesteps_at_once, 2, nt);
+  std::array<FullMatrix<Number>, 2> ret{{FullMatrix<Number>(2 * n, 2 * n), FullMatrix<Number>(2 * n, 2 * n)}};
+  auto idx = [&](unsigned v, unsigned k) { return s.index(k / nt, v, k % nt); };
+  for (unsigned a = 0; a < n; ++a)
+    for (unsigned b = 0; b < n; ++b) {
+      for (unsigned iv = 0; iv < 2; ++iv)
+        for (unsigned jv = 0; jv < 2; ++jv)
+          if (!(iv == 1 && jv == 1)) ret[0](idx(iv, a), idx(jv, b)) = tw[0](a, b);
+      ret[1](idx(0, a), idx(0, b)) = tw[1](a, b);
+    }
+  return ret;
+}
+
+// one device vector of a Stokes operator (velocity: 3 * n_velocity doubles, pressure: n_pressure)
+class StokesVector {
+public:
+  StokesVector() = default;
+  StokesVector(stfem_stokes_ctx *c, int variable) : c_(c), variable_(variable)
+  {
+    check(stfem_stokes_vector_create(c, variable, &d_), "stfem_stokes_vector_create");
+    n_ = variable == 0 ? 3 * size_t(stfem_stokes_n_velocity_dofs(c)) : size_t(stfem_stokes_n_pressure_dofs(c));
+  }
+  StokesVector(StokesVector &&o) noexcept : c_(o.c_), variable_(o.variable_), d_(o.d_), n_(o.n_) { o.d_ = nullptr; }
+  StokesVector &operator=(StokesVector &&o) noexcept
+  {
+    std::swap(c_, o.c_); std::swap(variable_, o.variable_); std::swap(d_, o.d_); std::swap(n_, o.n_);
+    return *this;
+  }
+  StokesVector(const StokesVector &) = delete;
+  ~StokesVector() { if (d_) stfem_stokes_vector_destroy(c_, d_); }
+  double *data() const { return d_; }
+  size_t size() const { return n_; }
+  void copy_from_host(const std::vector<double> &h)
+  {
+    if (h.size() != n_) throw std::invalid_argument("StokesVector size mismatch");
+    check(stfem_stokes_vector_upload(c_, variable_, d_, h.data()), "stfem_stokes_vector_upload");
+  }
+  std::vector<double> copy_to_host() const
+  {
+    std::vector<double> h(n_);
+    check(stfem_stokes_vector_download(c_, variable_, d_, h.data()), "stfem_stokes_vector_download");
+    return h;
+  }
+
+private:
+  stfem_stokes_ctx *c_ = nullptr;
+  int variable_ = 0;
+  double *d_ = nullptr;
+  size_t n_ = 0;
+};
+
+// operators.h:1193-1575 (cell loop; weak boundary ids / CIP faces are not built)
+template <int dim, typename Number> class StokesMatrixFreeOperator {
+  static_assert(dim == 3 && std::is_same<Number, double>::value, "3D, fp64");
+
+public:
+  using BlockVectorType = std::vector<StokesVector>; // {velocity, pressure}
+
+  StokesMatrixFreeOperator(const Mesh &mesh, unsigned velocity_degree, Number viscosity)
+  {
+    stfem_mesh_desc md{};
+    for (int d = 0; d < 3; ++d) {
+      md.ncell[d] = mesh.ncell[d];
+      md.lower[d] = mesh.lower[d];
+      md.upper[d] = mesh.upper[d];
+    }
+    md.vertices = mesh.vertices.empty() ? nullptr : mesh.vertices.data();
+    md.dirichlet_mask = mesh.dirichlet_mask;
+    md.device = mesh.device;
+    check(stfem_stokes_create(&md, int(velocity_degree), viscosity, &h_), "stfem_stokes_create");
+  }
+  ~StokesMatrixFreeOperator() { stfem_stokes_destroy(h_); }
+  StokesMatrixFreeOperator(const StokesMatrixFreeOperator &) = delete;
+
+  void initialize_dof_vector(BlockVectorType &vec) const // operators.h:1254-1262
+  {
+    vec.clear();
+    vec.emplace_back(h_, 0);
+    vec.emplace_back(h_, 1);
+  }
+  void initialize_dof_vector(StokesVector &vec, unsigned variable) const { vec = StokesVector(h_, int(variable)); }
+
+  void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    check(stfem_stokes_vmult(h_, dst.at(0).data(), dst.at(1).data(), src.at(0).data(), src.at(1).data(), stream),
+          "StokesMatrixFreeOperator::vmult");
+  }
+  // the MassMatrixType of SystemMatrixStokes (vector mass)
+  void mass_vmult(StokesVector &dst, const StokesVector &src, void *stream = nullptr) const
+  {
+    check(stfem_stokes_mass_vmult(h_, dst.data(), src.data(), stream), "vector mass vmult");
+  }
+  unsigned long long m() const { return 3ull * stfem_stokes_n_velocity_dofs(h_) + stfem_stokes_n_pressure_dofs(h_); }
+  stfem_stokes_ctx *handle() const { return h_; }
+
+private:
+  stfem_stokes_ctx *h_ = nullptr;
+};
+
+// operators.h:666-868; blocks in BlockSlice order
+template <int dim, typename Number> class SystemMatrixStokes {
+public:
+  using BlockVectorType = std::vector<StokesVector>;
+
+  SystemMatrixStokes(const StokesMatrixFreeOperator<dim, Number> &K, const FullMatrix<Number> &Alpha_,
+                     const FullMatrix<Number> &Beta_, const BlockSlice &blk_slice_)
+    : K(K), Alpha(Alpha_), Beta(Beta_), blk_slice(blk_slice_)
+  {
+    if (Alpha.m() != blk_slice.n_blocks() || Alpha.n() != Alpha.m() || Beta.m() != Alpha.m() || Beta.n() != Alpha.m())
+      throw std::invalid_argument("Alpha/Beta do not match the block slice");
+  }
+  void initialize_dof_vector(BlockVectorType &vec) const // operators.h:802-812
+  {
+    vec.clear();
+    for (unsigned i = 0; i < blk_slice.n_blocks(); ++i) vec.emplace_back(K.handle(), int(blk_slice.decompose(i)[1]));
+  }
+  void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    const unsigned nb = blk_slice.n_blocks();
+    if (dst.size() != nb || src.size() != nb) throw Error(STFEM_ERR_SHAPE_MISMATCH, "SystemMatrixStokes::vmult");
+    std::vector<double *> d(nb);
+    std::vector<const double *> s(nb);
+    for (unsigned i = 0; i < nb; ++i) { d[i] = dst[i].data(); s[i] = src[i].data(); }
+    check(stfem_stokes_st_vmult(K.handle(), int(blk_slice.n_timesteps_at_once()), int(blk_slice.n_timedofs()),
+                                blk_slice.variable_major() ? 1 : 0, Alpha.data(), Beta.data(), d.data(), s.data(), stream),
+          "SystemMatrixStokes::vmult");
+  }
+  unsigned long long m() const { return (unsigned long long)(blk_slice.n_blocks() / 2) * K.m(); }
+
+private:
+  const StokesMatrixFreeOperator<dim, Number> &K;
+  const FullMatrix<Number> &Alpha;
+  const FullMatrix<Number> &Beta;
+  BlockSlice blk_slice;
+};
+
+} // namespace stfem

@@ -18,6 +18,7 @@ def test_host_mirror_compiles():
         stfem.build()
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(HOST, "test_host_mirror"))
+    assert os.path.exists(os.path.join(HOST, "test_host_stokes"))
 
 
 @pytest.mark.gpu
@@ -48,3 +49,36 @@ def test_cpp_caller_matches_oracle(case, number, tmp_path, oracle_mod):
     g, z = (Gamma, Zeta) if ttype == 0 else (np.zeros_like(Gamma), Gamma)  # tests/tp_01.cc:160-166
     ref = orc.st_vmult(g, z, X[:1])
     assert rel(RHS, 2 * ref) < tol  # vmult_slice followed by vmult_slice_add
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [((3, 2, 4), 0, 2, 1, 0.5), ((2, 3, 2), 1, 1, 2, 2.0)])
+def test_cpp_stokes_caller_matches_oracle(case, tmp_path):
+    """SystemMatrixStokes / StokesMatrixFreeOperator mirror (host/stfem/stokes.h) vs the CPU oracle."""
+    from oracle import oracle
+    nc, ttype, r, ns, nu = case
+    stfem = importlib.import_module("dealii-stfem_amd")
+    exe = os.path.join(HOST, "test_host_stokes")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    out = tmp_path / "stokes.bin"
+    res = subprocess.run([exe, *map(str, nc), str(ttype), str(r), str(ns), str(nu), str(out)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    nb = int(raw[:8].view(np.uint64)[0])
+    off, X = 8, []
+    for _ in range(nb):
+        n = int(raw[off:off + 8].view(np.uint64)[0]); off += 8
+        X.append(raw[off:off + 8 * n].view(np.float64).copy()); off += 8 * n
+    Y = []
+    for b in range(nb):
+        n = X[b].size
+        Y.append(raw[off:off + 8 * n].view(np.float64).copy()); off += 8 * n
+    verts = stfem.mesh_vertices(nc, distort=0.1, seed=99)
+    orc = oracle.StokesOracle(nc, verts, 63, nu)
+    Alpha, Beta = stfem.get_fe_time_weights_stokes(ttype, r, 1.0 / 32, ns)
+    nt = r if ttype == 0 else r + 1
+    ref = orc.st_vmult(Alpha, Beta, ns, nt, X)
+    for b in range(nb):
+        assert np.linalg.norm(Y[b] - ref[b]) <= 1e-12 * np.linalg.norm(ref[b]), b
