@@ -25,7 +25,7 @@ struct Prec64 {
   using Plan = f64::TilePlan;
   using Diag = f64::DiagParams;
   static int atomic(int p, const Sweep &s, void *st) { return f64::launch_cart_atomic(p, s, st); }
-  static int geometry(int p, int nbm, Plan &pl) { return f64::tile_geometry(p, nbm, pl); }
+  static int geometry(int p, int nbm, int general, Plan &pl) { return f64::tile_geometry(p, nbm, general, pl); }
   static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f64::launch_cart_tile(p, s, pl, st); }
   static int diagonal(const Diag &d, void *st) { return f64::launch_diagonal(d, st); }
   static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
@@ -42,7 +42,7 @@ struct Prec32 {
   using Plan = f32::TilePlan;
   using Diag = f32::DiagParams;
   static int atomic(int p, const Sweep &s, void *st) { return f32::launch_cart_atomic(p, s, st); }
-  static int geometry(int p, int nbm, Plan &pl) { return f32::tile_geometry(p, nbm, pl); }
+  static int geometry(int p, int nbm, int general, Plan &pl) { return f32::tile_geometry(p, nbm, general, pl); }
   static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f32::launch_cart_tile(p, s, pl, st); }
   static int diagonal(const Diag &d, void *st) { return f32::launch_diagonal(d, st); }
   static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
@@ -521,7 +521,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         typename PR::Plan tp;
         std::memset(&tp, 0, sizeof(tp));
         const int nbm = std::max(tj, ti);
-        if (PR::geometry(c->p, nbm, tp) != 0) return STFEM_ERR_UNSUPPORTED;
+        if (PR::geometry(c->p, nbm, general ? 1 : 0, tp) != 0) return STFEM_ERR_UNSUPPORTED;
         plan_chunks(c, tp, nbm);
         const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
         const size_t ntiles = size_t(tp.ntx) * tp.nty * tp.ntc;

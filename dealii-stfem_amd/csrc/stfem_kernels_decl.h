@@ -73,8 +73,9 @@ struct DiagParams {
 };
 int launch_diagonal(const DiagParams &prm, void *stream);
 
-// Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm); returns 0 or -2.
-int tile_geometry(int p, int nbm, TilePlan &plan);
+// Variant "tile" (default): fills plan.cw/rows/tX/tY for (p, nbm) and the Cartesian (general = 0) or
+// general-geometry kernel; returns 0 or -2.
+int tile_geometry(int p, int nbm, int general, TilePlan &plan);
 int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);
 // fills metric[cell][q][8] from the vertex grid (device pointers); coef_* may be null,
 // layout 1 = per cell, 2 = per (cell, q)

@@ -42,30 +42,36 @@ constexpr int tile_cells_per_wave(int p, int nbm)
   const int cpw = (64 / (p + 1)) / nbm;
   return p * cpw + 1 > 64 ? 63 / p : cpw;
 }
-// Two ways to a tile row of two wave-widths, both measured no faster than the plain tile on cfg 1
-// (0.47 vs 0.47 ms; the 8-wave workgroup 0.51 ms) and therefore off by default:
-//   -DSTFEM_TILE_WIDE_WG  two waves side by side (8-wave workgroup, one per CU);
-//   -DSTFEM_TILE_SX2      every wave handles two cell groups one after the other (Cartesian path only).
+// Tile rows of two wave-widths.  Every wave handles SX = 2 cell groups one after the other on the
+// fp64 Cartesian path: rows of 49 instead of 25 doubles for Q4 x 2 blocks, -20 % HBM fetch, half
+// the 32-byte partial writes, 7 % less time on cfg 1 (A/B on one box: 0.473 -> 0.440 ms).  Not
+// on the general path (metric-bound anyway; its fp64 instantiation fails parity with SX = 2, not
+// understood yet) and not in fp32 (128-VGPR budget).  -DSTFEM_TILE_WIDE_WG instead puts two waves
+// side by side (8-wave workgroup, one per CU): measured slower, its compute and memory phases no
+// longer overlap with a second workgroup's.
 #if defined(STFEM_TILE_WIDE_WG)
 constexpr int tile_wx(int p, int nbm) { return p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64 ? 2 : 1; }
-constexpr int tile_sx(int, int) { return 1; }
-#elif defined(STFEM_TILE_SX2)
+constexpr int tile_sx(int, int, bool) { return 1; }
+#elif defined(STFEM_F32) || defined(STFEM_TILE_SX1)
 constexpr int tile_wx(int, int) { return 1; }
-constexpr int tile_sx(int p, int nbm) { return p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64 ? 2 : 1; }
+constexpr int tile_sx(int, int, bool) { return 1; }
 #else
 constexpr int tile_wx(int, int) { return 1; }
-constexpr int tile_sx(int, int) { return 1; }
+constexpr int tile_sx(int p, int nbm, bool general)
+{
+  return (!general && nbm <= 3 && p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64) ? 2 : 1; // more blocks spill
+}
 #endif
 
 constexpr int tile_threads(int p, int nbm) { return 256 * tile_wx(p, nbm); }
 constexpr int tile_min_blocks(int p, int nbm, int minw) { return minw / tile_wx(p, nbm) > 0 ? minw / tile_wx(p, nbm) : 1; }
 
-template <int P, int NBM> struct TileGeom {
+template <int P, int NBM, bool GEN> struct TileGeom {
   using G = Geometry<P, NBM>;
   static constexpr int N = P + 1;
   static constexpr int CWW = tile_cells_per_wave(P, NBM); // cells per wave
   static constexpr int WX = tile_wx(P, NBM);              // waves per cell row
-  static constexpr int SX = tile_sx(P, NBM);              // cell groups a wave handles in turn
+  static constexpr int SX = tile_sx(P, NBM, GEN);              // cell groups a wave handles in turn
   static constexpr int ROWS = 4;                           // cell rows (waves along y)
   static constexpr int NWAVES = WX * ROWS;
   static constexpr int NT = 64 * NWAVES;                   // threads per workgroup
@@ -196,7 +202,7 @@ template <int P, int NBM, int MINW, bool ADD, bool COEF, bool GEN, int COLOR>
 __global__ __launch_bounds__(tile_threads(P, NBM), tile_min_blocks(P, NBM, MINW))
 void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 {
-  using TG = TileGeom<P, NBM>;
+  using TG = TileGeom<P, NBM, GEN>;
   using G = Geometry<P, NBM>;
   constexpr int N = TG::N;
   constexpr int NT = TG::NT, LPR = TG::LPR, RPI = TG::RPI, RPP = TG::RPP;
@@ -374,6 +380,13 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     }
 
     STFEM_TL(1);
+#ifdef STFEM_EARLY_PREFETCH // experiment: the next layer's gather is issued before the core, into a second buffer
+    real_t PB[SX][N * N];
+    if (!last_layer && !(ex & 1)) {
+      STFEM_UNROLL
+      for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PB[h]);
+    }
+#endif
     STFEM_UNROLL
     for (int h = 0; h < SX; ++h) {
       real_t aK[NBM], aM[NBM];
@@ -467,10 +480,22 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     }
     // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
     // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
+#ifdef STFEM_EARLY_PREFETCH
+    if (!last_layer && !(ex & 1)) {
+      wait_vmcnt_imm<0>();
+      STFEM_UNROLL
+      for (int h = 0; h < SX; ++h) {
+        pin(PB[h]);
+        STFEM_UNROLL
+        for (int e = 0; e < N * N; ++e) PA[h][e] = PB[h][e];
+      }
+    }
+#else
     if (!last_layer && !(ex & 1)) {
       STFEM_UNROLL
       for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA[h]);
     }
+#endif
     STFEM_TL(6);
     STFEM_LAYER_BARRIER();
     STFEM_TL(7);
@@ -629,7 +654,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
       int n_o = 0;
       STFEM_UNROLL
       for (int o = 0; o < (TY + RPP - 1) / RPP; ++o) n_o += (RPI * wave_u + RPP * o < ymax) ? 1 : 0;
-#ifndef STFEM_F32
+#if !defined(STFEM_F32) && !defined(STFEM_EARLY_PREFETCH)
       wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
 #else
       (void)n_o;
@@ -706,9 +731,9 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
 #define STFEM_LAUNCH(WW, AA, CC, GG)                                                                        \
   do {                                                                                                     \
     if (colour == 1)                                                                                       \
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 1>), dim3(nblocks), dim3(TileGeom<P, NBM>::NT), 0, st, prm, tp); \
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 1>), dim3(nblocks), dim3(TileGeom<P, NBM, GG>::NT), 0, st, prm, tp); \
     else                                                                                                   \
-      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 0>), dim3(nblocks), dim3(TileGeom<P, NBM>::NT), 0, st, prm, tp); \
+      hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 0>), dim3(nblocks), dim3(TileGeom<P, NBM, GG>::NT), 0, st, prm, tp); \
   } while (0)
     if (prm.metric) { // general geometry / per-q coefficients (baked into the metric)
       if (tp.add) STFEM_LAUNCH(1, true, false, true);
@@ -815,7 +840,7 @@ int launch_build_metric(int p, const int nc[3], const double *d_vertices, const 
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int tile_geometry(int p, int nbm, TilePlan &plan)
+int tile_geometry(int p, int nbm, int general, TilePlan &plan)
 {
   if (p < 1 || p > 4) return -2;
   nbm = round_nbm(nbm);
@@ -824,7 +849,7 @@ int tile_geometry(int p, int nbm, TilePlan &plan)
   if (nbm > cb) return -2;
   // the store phase maps one slab row to at most 64 lanes
   plan.wx = tile_wx(p, nbm);
-  plan.cw = plan.wx * tile_sx(p, nbm) * tile_cells_per_wave(p, nbm);
+  plan.cw = plan.wx * tile_sx(p, nbm, general != 0) * tile_cells_per_wave(p, nbm);
   plan.rows = 4;
   plan.tX = p * plan.cw + 1;
   plan.tY = p * plan.rows + 1;

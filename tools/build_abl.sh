@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../dealii-stfem_amd/csrc"
 mkdir -p build_abl
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=fast -DSTFEM_ABLATION $@"
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=fast ${ABL--DSTFEM_ABLATION} $@"
 /opt/rocm/bin/hipcc $FL -DSTFEM_TILE_P=4 -c -o build_abl/stfem_tile_p4.o stfem_tile.hip &
 /opt/rocm/bin/hipcc $FL -c -o build_abl/stfem_tile.o stfem_tile.hip &
 wait
