@@ -699,21 +699,49 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
     const real_t *zh_z = tp.zh + (int64_t(tid_z) * nbm + j) * sz;   // (tx, ty, tc-1)
     // the same slabs of the tiles at tx - 1 (one tile earlier in the numbering)
     const int64_t left_y = int64_t(nbm) * sy, left_z = int64_t(nbm) * sz;
+    // four rows per thread in flight (the loop is a chain of dependent load -> add -> store otherwise)
+    constexpr int U = 4;
     if (has_y) // rows Y = 0, Z >= (has_z ? 1 : 0): contributions of the tiles below in y
-      for (int Z = rg + has_z; Z < Zn; Z += nrg) {
-        real_t s = yh_y[Z * tp.tX + X];
-        if (dxn) s += (yh_y - left_y)[Z * tp.tX + XpL];
-        d[plane_stride * Z] += s;
+      for (int Z0 = rg + has_z; Z0 < Zn; Z0 += U * nrg) {
+        real_t s[U], v[U];
+        STFEM_UNROLL
+        for (int u = 0; u < U; ++u) {
+          const int Z = Z0 + u * nrg;
+          s[u] = v[u] = real_t(0);
+          if (Z < Zn) {
+            s[u] = yh_y[Z * tp.tX + X];
+            if (dxn) s[u] += (yh_y - left_y)[Z * tp.tX + XpL];
+            v[u] = d[plane_stride * Z];
+          }
+        }
+        STFEM_UNROLL
+        for (int u = 0; u < U; ++u) {
+          const int Z = Z0 + u * nrg;
+          if (Z < Zn) d[plane_stride * Z] = v[u] + s[u];
+        }
       }
     if (has_z) // plane Z = 0: tiles below in z, and for its row Y = 0 also below in y
-      for (int Y = rg; Y < Yn; Y += nrg) {
-        real_t s = zh_z[Y * tp.tX + X];
-        if (dxn) s += (zh_z - left_z)[Y * tp.tX + XpL];
-        if (Y == 0 && has_y) {
-          s += yh_y[X] + yh_yz[top_below * tp.tX + X];
-          if (dxn) s += (yh_y - left_y)[XpL] + (yh_yz - left_y)[top_below * tp.tX + XpL];
+      for (int Y0 = rg; Y0 < Yn; Y0 += U * nrg) {
+        real_t s[U], v[U];
+        STFEM_UNROLL
+        for (int u = 0; u < U; ++u) {
+          const int Y = Y0 + u * nrg;
+          s[u] = v[u] = real_t(0);
+          if (Y < Yn) {
+            s[u] = zh_z[Y * tp.tX + X];
+            if (dxn) s[u] += (zh_z - left_z)[Y * tp.tX + XpL];
+            if (Y == 0 && has_y) {
+              s[u] += yh_y[X] + yh_yz[top_below * tp.tX + X];
+              if (dxn) s[u] += (yh_y - left_y)[XpL] + (yh_yz - left_y)[top_below * tp.tX + XpL];
+            }
+            v[u] = d[int64_t(prm.nx) * Y];
+          }
         }
-        d[int64_t(prm.nx) * Y] += s;
+        STFEM_UNROLL
+        for (int u = 0; u < U; ++u) {
+          const int Y = Y0 + u * nrg;
+          if (Y < Yn) d[int64_t(prm.nx) * Y] = v[u] + s[u];
+        }
       }
   }
 }
