@@ -97,6 +97,8 @@ SIGNATURES = {
     "stfem_stokes_mass_vmult": (C.c_int, [_vp, _vp, _vp, _vp]),
     "stfem_stokes_st_vmult": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.POINTER(_vp),
                                         C.POINTER(_vp), _vp]),
+    "stfem_stokes_st_vmult_slice_add": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.POINTER(_vp),
+                                                  _vp, _vp, _vp]),
     "stfem_stokes_last_hip_error": (C.c_char_p, []),
     "stfem_strerror": (C.c_char_p, [C.c_int]),
     "stfem_last_hip_error": (C.c_char_p, []),
@@ -421,6 +423,19 @@ class StokesMatrixFreeOperator:
         s_ = (_vp * nb)(*[getattr(v, "ptr", v) for v in src_blocks])
         _check(lib().stfem_stokes_st_vmult(self._h, n_timesteps_at_once, n_timedofs, int(variable_major),
                                            _p(A), _p(B), d, s_, stream), "stfem_stokes_st_vmult")
+
+    def st_vmult_slice_add(self, Gamma, Zeta, n_timesteps_at_once, n_timedofs, dst_blocks, src_u, src_p,
+                           variable_major=True, stream=None):
+        """SystemMatrixStokes::vmult_slice_add (n x 1 right-hand-side case); dst is accumulated into."""
+        nb = 2 * n_timesteps_at_once * n_timedofs
+        g = np.ascontiguousarray(Gamma, dtype=np.float64).reshape(-1)
+        z = np.ascontiguousarray(Zeta, dtype=np.float64).reshape(-1)
+        assert g.size == nb and z.size == nb and len(dst_blocks) == nb
+        d = (_vp * nb)(*[getattr(v, "ptr", v) for v in dst_blocks])
+        _check(lib().stfem_stokes_st_vmult_slice_add(self._h, n_timesteps_at_once, n_timedofs, int(variable_major),
+                                                     _p(g), _p(z), d, getattr(src_u, "ptr", src_u),
+                                                     getattr(src_p, "ptr", src_p), stream),
+               "stfem_stokes_st_vmult_slice_add")
 
 
 class StokesVector:

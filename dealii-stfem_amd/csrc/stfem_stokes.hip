@@ -471,4 +471,47 @@ int stfem_stokes_st_vmult(stfem_stokes_ctx *c, int n_timesteps_at_once, int n_ti
   return STFEM_OK;
 }
 
+// SystemMatrixStokes::vmult_slice_add (operators.h:748-781): the n x 1 case used for the right-hand
+// side: src = one (velocity, pressure) pair, dst[index(it,v,id)] += Gamma(index(it,v,id), 0) * (K_S src)_v
+// and dst[index(it,0,id)] += Zeta(index(it,0,id), 0) * M u.  dst is NOT zeroed.
+int stfem_stokes_st_vmult_slice_add(stfem_stokes_ctx *c, int n_timesteps_at_once, int n_timedofs, int variable_major,
+                                    const double *Gamma, const double *Zeta, double *const *dst_blocks,
+                                    const double *src_u, const double *src_p, void *stream)
+{
+  if (!c || !Gamma || !Zeta || !dst_blocks || !src_u || !src_p || n_timesteps_at_once < 1 || n_timedofs < 1)
+    return STFEM_ERR_INVALID_ARGUMENT;
+  const int nt = n_timedofs, ns = n_timesteps_at_once, nb = 2 * nt * ns;
+  auto index = [&](int it, int v, int d) { return variable_major ? it * (2 * nt) + v * nt + d : it * (2 * nt) + d * 2 + v; };
+  for (int j = 0; j < nb; ++j) {
+    if (!dst_blocks[j]) return STFEM_ERR_INVALID_ARGUMENT;
+    if (dst_blocks[j] == src_u || dst_blocks[j] == src_p) return STFEM_ERR_ALIAS;
+  }
+  STOKES_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double eps10 = 10 * std::numeric_limits<double>::epsilon();
+  StokesParams prm = c->base;
+  prm.u = src_u;
+  prm.p = src_p;
+  prm.nout = 0;
+  for (int it = 0; it < ns; ++it)
+    for (int id = 0; id < nt; ++id) {
+      const int ju = index(it, 0, id), jp = index(it, 1, id);
+      const double aU = Gamma[ju], aP = Gamma[jp], bU = Zeta[ju];
+      const bool useU = std::abs(aU) > eps10, useP = std::abs(aP) > eps10, useM = std::abs(bU) > eps10;
+      if (!useU && !useP && !useM) continue;
+      const int o = prm.nout++;
+      prm.out_u[o] = (useU || useM) ? dst_blocks[ju] : nullptr;
+      prm.out_p[o] = useP ? dst_blocks[jp] : nullptr;
+      prm.wKu[o] = useU ? aU : 0.0;
+      prm.wKp[o] = useP ? aP : 0.0;
+      prm.wM[o] = useM ? bU : 0.0;
+      if (prm.nout == MAXOUT) {
+        const int rc = stokes_launch(c, prm, st);
+        if (rc != STFEM_OK) return rc;
+        prm.nout = 0;
+      }
+    }
+  return prm.nout ? stokes_launch(c, prm, st) : STFEM_OK;
+}
+
 } // extern "C"

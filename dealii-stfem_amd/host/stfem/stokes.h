@@ -153,7 +153,8 @@ public:
                      const FullMatrix<Number> &Beta_, const BlockSlice &blk_slice_)
     : K(K), Alpha(Alpha_), Beta(Beta_), blk_slice(blk_slice_)
   {
-    if (Alpha.m() != blk_slice.n_blocks() || Alpha.n() != Alpha.m() || Beta.m() != Alpha.m() || Beta.n() != Alpha.m())
+    if (Alpha.m() != blk_slice.n_blocks() || (Alpha.n() != Alpha.m() && Alpha.n() != 1) || Beta.m() != Alpha.m() ||
+        Beta.n() != Alpha.n())
       throw std::invalid_argument("Alpha/Beta do not match the block slice");
   }
   void initialize_dof_vector(BlockVectorType &vec) const // operators.h:802-812
@@ -171,6 +172,19 @@ public:
     check(stfem_stokes_st_vmult(K.handle(), int(blk_slice.n_timesteps_at_once()), int(blk_slice.n_timedofs()),
                                 blk_slice.variable_major() ? 1 : 0, Alpha.data(), Beta.data(), d.data(), s.data(), stream),
           "SystemMatrixStokes::vmult");
+  }
+  // n x 1 case for the right-hand side (operators.h:748-781): Alpha, Beta are n x 1 here and src is one
+  // (velocity, pressure) pair; dst is accumulated into
+  void vmult_slice_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    const unsigned nb = blk_slice.n_blocks();
+    if (dst.size() != nb || src.size() != 2 || Alpha.n() != 1) throw Error(STFEM_ERR_SHAPE_MISMATCH, "vmult_slice_add");
+    std::vector<double *> d(nb);
+    for (unsigned i = 0; i < nb; ++i) d[i] = dst[i].data();
+    check(stfem_stokes_st_vmult_slice_add(K.handle(), int(blk_slice.n_timesteps_at_once()), int(blk_slice.n_timedofs()),
+                                          blk_slice.variable_major() ? 1 : 0, Alpha.data(), Beta.data(), d.data(),
+                                          src[0].data(), src[1].data(), stream),
+          "SystemMatrixStokes::vmult_slice_add");
   }
   unsigned long long m() const { return (unsigned long long)(blk_slice.n_blocks() / 2) * K.m(); }
 

@@ -204,6 +204,14 @@ int stfem_stokes_mass_vmult(stfem_stokes_ctx *ctx, double *dst_u, const double *
 int stfem_stokes_st_vmult(stfem_stokes_ctx *ctx, int n_timesteps_at_once, int n_timedofs,
                           int variable_major, const double *Alpha, const double *Beta,
                           double *const *dst_blocks, const double *const *src_blocks, void *stream);
+/* SystemMatrixStokes::vmult_slice_add (operators.h:748-781), the n x 1 case of the right-hand side:
+ * Gamma, Zeta are host vectors of 2*nt*ns entries (column 0 of the reference's n x 1 matrices);
+ *   dst[index(it,v,id)] += Gamma[index(it,v,id)] * (K_S (u,p))_v ,  dst[index(it,0,id)] += Zeta[index(it,0,id)] * M u
+ * dst is not zeroed. */
+int stfem_stokes_st_vmult_slice_add(stfem_stokes_ctx *ctx, int n_timesteps_at_once, int n_timedofs,
+                                    int variable_major, const double *Gamma, const double *Zeta,
+                                    double *const *dst_blocks, const double *src_u,
+                                    const double *src_p, void *stream);
 const char *stfem_stokes_last_hip_error(void);
 
 const char *stfem_strerror(int status);

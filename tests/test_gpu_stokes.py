@@ -101,3 +101,28 @@ def test_stokes_errors(stfem):
     with pytest.raises(stfem.StfemError) as e:
         stfem.StokesMatrixFreeOperator((2, 2, 2), velocity_degree=3)
     assert e.value.status == -2  # STFEM_ERR_UNSUPPORTED
+
+
+def test_stokes_vmult_slice_add(stfem):
+    """n x 1 right-hand-side case (operators.h:748-781) against the oracle's spatial apply."""
+    from oracle import oracle
+    nc = (3, 4, 2)
+    verts = stfem.mesh_vertices(nc, distort=0.1, seed=3)
+    op = stfem.StokesMatrixFreeOperator(nc, vertices=verts, dirichlet_mask=63, viscosity=1.7)
+    orc = oracle.StokesOracle(nc, verts, 63, 1.7)
+    ns, nt = 2, 2
+    nb = 2 * ns * nt
+    rng = np.random.default_rng(11)
+    Gamma, Zeta = rng.uniform(-1, 1, nb), rng.uniform(-1, 1, nb)
+    Gamma[stfem.stokes_block_index(nt, 1, 1, 0)] = 0.0  # a skipped entry
+    U, Pp = rng.uniform(-1, 1, 3 * orc.n_u), rng.uniform(-1, 1, orc.n_p)
+    ku, kp = orc.apply(U, Pp)
+    mu, _ = orc.apply(U, Pp, 0.0, 1.0)
+    init = [rng.uniform(-1, 1, 3 * orc.n_u if (j // nt) % 2 == 0 else orc.n_p) for j in range(nb)]
+    dst = [op.initialize_dof_vector((j // nt) % 2, init[j]) for j in range(nb)]
+    op.st_vmult_slice_add(Gamma, Zeta, ns, nt, dst, op.initialize_dof_vector(0, U), op.initialize_dof_vector(1, Pp))
+    for it in range(ns):
+        for d in range(nt):
+            ju, jp = stfem.stokes_block_index(nt, it, 0, d), stfem.stokes_block_index(nt, it, 1, d)
+            assert rel(dst[ju].download(), init[ju] + Gamma[ju] * ku.reshape(-1) + Zeta[ju] * mu.reshape(-1)) < TOL
+            assert rel(dst[jp].download(), init[jp] + Gamma[jp] * kp) < TOL
