@@ -52,7 +52,7 @@ constexpr int tile_cells_per_wave(int p, int nbm)
 #if defined(STFEM_TILE_WIDE_WG)
 constexpr int tile_wx(int p, int nbm) { return p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64 ? 2 : 1; }
 constexpr int tile_sx(int, int, bool) { return 1; }
-#elif defined(STFEM_F32) || defined(STFEM_TILE_SX1)
+#elif (defined(STFEM_F32) && !defined(STFEM_F32_SX2)) || defined(STFEM_TILE_SX1)
 constexpr int tile_wx(int, int) { return 1; }
 constexpr int tile_sx(int, int, bool) { return 1; }
 #else
@@ -784,7 +784,11 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
 {
 #ifdef STFEM_F32
   // half the registers and half the LDS per workgroup: twice the waves per SIMD
+#ifdef STFEM_F32_WAVES
+  return launch_tile_w<P, NBM, STFEM_F32_WAVES>(prm, tp, st);
+#else
   return launch_tile_w<P, NBM, 4>(prm, tp, st);
+#endif
 #else
   return tile_wg_per_cu(P, NBM) == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
 #endif

@@ -15,12 +15,13 @@ t = raw[4:].reshape(nblk, nw, lz, ns)
 used = t[:, 0, 0, 0] > 0
 t = t[used]
 print(f"{t.shape[0]} recorded workgroups x {nw} waves x {lz} layers; tick = 10 ns")
-d = np.diff(t[..., :12], axis=-1).astype(float) / 100.0  # us
-tot = (t[..., 11] - t[..., 0]) / 100.0
+lay_ok = t[..., 0] > 0
+d = np.diff(t[..., :12], axis=-1).astype(float)[lay_ok] / 100.0  # us
+tot = ((t[..., 11] - t[..., 0])[lay_ok]) / 100.0
 print(f"layer time (0->11): mean {tot.mean():.2f} us, median {np.median(tot):.2f}, p90 {np.percentile(tot, 90):.2f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:36s} mean {d[..., i].mean():6.2f} us  median {np.median(d[..., i]):6.2f}  p90 {np.percentile(d[..., i], 90):6.2f}")
-wg_start, wg_end = t[:, :, 0, 0].min(1), t[:, :, -1, 11].max(1)
+wg_start, wg_end = t[:, :, 0, 0].min(1), t[:, :, :, 11].max(axis=(1, 2))
 print(f"workgroup lifetime mean {(wg_end - wg_start).mean() / 100:.1f} us; kernel span {(wg_end.max() - wg_start.min()) / 100:.1f} us")
 # which CU: HW_ID cu_id[11:8] sh_id[12] se_id[15:13] (gfx9 layout), XCC_ID low bits
 hw = t[:, 0, 0, 15]
@@ -43,7 +44,9 @@ print("first CU: workgroup start/end (us rel.):", [(round((wg_start[i] - wg_star
 # do the workgroups march in lockstep?  fraction of live workgroups (wave 0) inside the cell core /
 # inside a memory-issuing phase, sampled every microsecond
 t0 = t[:, 0, :, :12]
-lo, hi = t0[..., 0].min(), t0[..., 11].max()
+valid = t0[..., 0] > 0  # chunks shorter than the longest leave unused layer slots at zero
+lo, hi = t0[..., 0][valid].min(), t0[..., 11][valid].max()
+assert hi - lo < 10 ** 8, (lo, hi)
 ticks = np.arange(lo, hi, 100)
 core = np.zeros(len(ticks)); mem = np.zeros(len(ticks)); alive = np.zeros(len(ticks))
 for w in range(t0.shape[0]):
@@ -61,3 +64,6 @@ fc, fm = core[ok] / alive[ok], mem[ok] / alive[ok]
 print(f"fraction of live workgroups in the core: mean {fc.mean():.2f} min {fc.min():.2f} max {fc.max():.2f} std {fc.std():.3f}")
 print(f"fraction in gather-issue / store phases: mean {fm.mean():.2f} min {fm.min():.2f} max {fm.max():.2f} std {fm.std():.3f}")
 print("core fraction per us (first 60):", " ".join(f"{x:.2f}" for x in fc[:60]))
+
+# average number of workgroups resident on the chip = sum of lifetimes / kernel span
+print(f"mean resident workgroups: {(wg_end - wg_start).sum() / (wg_end.max() - wg_start.min()):.1f}")
