@@ -26,6 +26,13 @@ struct Prec64 {
   using Diag = f64::DiagParams;
   static int atomic(int p, const Sweep &s, void *st) { return f64::launch_cart_atomic(p, s, st); }
   static int geometry(int p, int nbm, int general, Plan &pl) { return f64::tile_geometry(p, nbm, general, pl); }
+  static int occupancy(int p, int nbm, int general)
+  {
+    static int cache[5][stfem::MAX_BLOCKS + 1][2] = {}; // 0 = not asked yet (one device type per process)
+    int &v = cache[p][nbm][general];
+    if (v == 0) v = std::max(1, f64::tile_occupancy(p, nbm, general)) + 100;
+    return v - 100;
+  }
   static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f64::launch_cart_tile(p, s, pl, st); }
   static int diagonal(const Diag &d, void *st) { return f64::launch_diagonal(d, st); }
   static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
@@ -43,6 +50,13 @@ struct Prec32 {
   using Diag = f32::DiagParams;
   static int atomic(int p, const Sweep &s, void *st) { return f32::launch_cart_atomic(p, s, st); }
   static int geometry(int p, int nbm, int general, Plan &pl) { return f32::tile_geometry(p, nbm, general, pl); }
+  static int occupancy(int p, int nbm, int general)
+  {
+    static int cache[5][stfem::MAX_BLOCKS + 1][2] = {};
+    int &v = cache[p][nbm][general];
+    if (v == 0) v = std::max(1, f32::tile_occupancy(p, nbm, general)) + 100;
+    return v - 100;
+  }
   static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f32::launch_cart_tile(p, s, pl, st); }
   static int diagonal(const Diag &d, void *st) { return f32::launch_diagonal(d, st); }
   static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
@@ -394,9 +408,9 @@ template <class PR> static void fill_common(const stfem_ctx *c, typename PR::Swe
 
 // Chooses the z-chunking of the tile variant.  One colour launch has columns x ntc workgroups of
 // ceil(ncz / ntc) layers (+ about one layer of start-up) that run in rounds of `slots` resident
-// workgroups; a layer takes about as long with three workgroups on a CU as with two, so what
+// workgroups (`resident` per CU: what the runtime reports for the kernel, 2 if unknown); what
 // matters is that the last round is full.  Fewer chunks win ties (smaller z-halo).
-template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm)
+template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm, int resident)
 {
   tp.ntx = (c->nc[0] + tp.cw - 1) / tp.cw;
   tp.nty = (c->nc[1] + tp.rows - 1) / tp.rows;
@@ -406,7 +420,8 @@ template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm)
     const int lz = std::max(1, std::min(ncz, atoi(e)));
     ntc = (ncz + lz - 1) / lz;
   } else {
-    const int wpc = std::max(1, (c->prec ? 4 : stfem::tile_wg_per_cu(c->p, nbm)) / std::max(1, tp.wx));
+    (void)nbm;
+    const int wpc = std::max(2, resident); // (planning one-per-CU kernels in rounds of 256 measured 5 % slower)
     const int64_t slots = int64_t(c->n_cu > 0 ? c->n_cu : 256) * wpc;
     const int64_t columns = int64_t((tp.ntx + 1) / 2) * tp.nty; // of the larger colour
     double best = 1e300;
@@ -522,7 +537,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         std::memset(&tp, 0, sizeof(tp));
         const int nbm = std::max(tj, ti);
         if (PR::geometry(c->p, nbm, general ? 1 : 0, tp) != 0) return STFEM_ERR_UNSUPPORTED;
-        plan_chunks(c, tp, nbm);
+        plan_chunks(c, tp, nbm, PR::occupancy(c->p, nbm, general ? 1 : 0));
         const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
         const size_t ntiles = size_t(tp.ntx) * tp.nty * tp.ntc;
         const size_t nyh = ntiles * nbm_r * tp.zp * tp.tX, nzh = ntiles * nbm_r * tp.tY * tp.tX,

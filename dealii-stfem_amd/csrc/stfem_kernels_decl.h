@@ -77,6 +77,8 @@ int launch_diagonal(const DiagParams &prm, void *stream);
 // general-geometry kernel; returns 0 or -2.
 int tile_geometry(int p, int nbm, int general, TilePlan &plan);
 int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream);
+// workgroups of the sweep kernel that fit one CU according to the runtime (0 if unknown)
+int tile_occupancy(int p, int nbm, int general);
 // fills metric[cell][q][8] from the vertex grid (device pointers); coef_* may be null,
 // layout 1 = per cell, 2 = per (cell, q)
 int launch_build_metric(int p, const int nc[3], const double *d_vertices, const double *d_xq,

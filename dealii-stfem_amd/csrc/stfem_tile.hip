@@ -25,6 +25,7 @@
 // dst.add(...) traffic of SystemMatrix::vmult (operators.h:536-559).
 #include "stfem_core.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 #ifndef STFEM_TILE_P
@@ -40,7 +41,11 @@ namespace {
 constexpr int tile_cells_per_wave(int p, int nbm)
 {
   const int cpw = (64 / (p + 1)) / nbm;
+#ifdef STFEM_TILE_CPW_MINUS1 // experiment: one cell less per wave (Q4 x 2 blocks: 40 000 B of LDS per workgroup)
+  return cpw > 1 ? cpw - 1 : cpw;
+#else
   return p * cpw + 1 > 64 ? 63 / p : cpw;
+#endif
 }
 // Tile rows of two wave-widths.  Every wave handles SX = 2 cell groups one after the other on the
 // fp64 Cartesian path: rows of 49 instead of 25 doubles for Q4 x 2 blocks, -20 % HBM fetch, half
@@ -83,7 +88,8 @@ template <int P, int NBM, bool GEN> struct TileGeom {
   static constexpr int TY = P * ROWS + 1;
   static constexpr int PLANE = TX * TY;
   static constexpr int ACC = NBM * N * PLANE;              // accumulation slab (aliases trans)
-  static constexpr int TRANS = NWAVES * G::LDS_PER_WAVE;   // transpose slabs
+  static constexpr int LDS_PER_WAVE = CWW * NBM * G::CBS;  // transpose slab of one wave
+  static constexpr int TRANS = NWAVES * LDS_PER_WAVE;      // transpose slabs
   static constexpr int MAIN = ACC > TRANS ? ACC : TRANS;
   static constexpr int CARRY = NBM * PLANE;                // top plane carried between layers
   static constexpr int CARRY_REGS = (CARRY + NT - 1) / NT; // ... in registers, CARRY_REGS per thread
@@ -213,7 +219,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  real_t *lds = smem + wave * G::LDS_PER_WAVE;
+  real_t *lds = smem + wave * TG::LDS_PER_WAVE;
 
   // tiles of this launch's x colour
   const int ntxh = (tp.ntx - COLOR + 1) / 2; // tiles of this launch's x colour
@@ -780,6 +786,47 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
   return 0;
 }
 
+// Workgroups of the sweep kernel the runtime can keep resident on one CU (registers, LDS): what the
+// z-chunk planner fills its rounds with.  STFEM_DEBUG_OCC=1 prints the kernel's resources.
+template <int P, int NBM, int WV> int tile_occupancy_w(bool general)
+{
+  int n = 0;
+  hipError_t e;
+  const void *kern;
+  if (general) {
+    auto k = st_sweep_cart_tile<P, NBM, 1, false, false, true, 0>;
+    kern = reinterpret_cast<const void *>(k);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, TileGeom<P, NBM, true>::NT, 0);
+  } else {
+    auto k = st_sweep_cart_tile<P, NBM, WV, false, false, false, 0>;
+    kern = reinterpret_cast<const void *>(k);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, TileGeom<P, NBM, false>::NT, 0);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  if (getenv("STFEM_DEBUG_OCC")) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kern) == hipSuccess)
+      fprintf(stderr, "st_sweep_cart_tile<%d,%d,%s>: %d workgroups/CU; %d registers, %zu B LDS, %zu B scratch\n", P, NBM,
+              general ? "general" : "cartesian", n, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+  }
+  return n;
+}
+template <int P, int NBM> int tile_occupancy_t(bool general)
+{
+#ifdef STFEM_F32
+#ifdef STFEM_F32_WAVES
+  return tile_occupancy_w<P, NBM, STFEM_F32_WAVES>(general);
+#else
+  return tile_occupancy_w<P, NBM, 4>(general);
+#endif
+#else
+  return tile_wg_per_cu(P, NBM) == 3 ? tile_occupancy_w<P, NBM, 3>(general) : tile_occupancy_w<P, NBM, 2>(general);
+#endif
+}
+
 template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePlan &tp, hipStream_t st)
 {
 #ifdef STFEM_F32
@@ -909,7 +956,34 @@ int STFEM_PASTE(launch_cart_tile_p, STFEM_TILE_P)(const SweepParams &prm, const 
 #undef STFEM_CASE
   return -2;
 }
+int STFEM_PASTE(tile_occupancy_p, STFEM_TILE_P)(int nbm_in, int general)
+{
+  const int nbm = round_nbm(nbm_in);
+#define STFEM_CASE(NB) \
+  if (nbm == NB) return tile_occupancy_t<STFEM_TILE_P, NB>(general != 0);
+#ifdef STFEM_QUICK
+  STFEM_CASE(2)
 #else
+  STFEM_CASE(1) STFEM_CASE(2) STFEM_CASE(3) STFEM_CASE(4) STFEM_CASE(6) STFEM_CASE(8)
+#endif
+#undef STFEM_CASE
+  return 0;
+}
+#else
+int tile_occupancy_p1(int, int);
+int tile_occupancy_p2(int, int);
+int tile_occupancy_p3(int, int);
+int tile_occupancy_p4(int, int);
+int tile_occupancy(int p, int nbm, int general)
+{
+  switch (p) {
+    case 1: return tile_occupancy_p1(nbm, general);
+    case 2: return tile_occupancy_p2(nbm, general);
+    case 3: return tile_occupancy_p3(nbm, general);
+    case 4: return tile_occupancy_p4(nbm, general);
+    default: return 0;
+  }
+}
 int launch_cart_tile_p1(const SweepParams &, const TilePlan &, hipStream_t);
 int launch_cart_tile_p2(const SweepParams &, const TilePlan &, hipStream_t);
 int launch_cart_tile_p3(const SweepParams &, const TilePlan &, hipStream_t);

@@ -67,3 +67,8 @@ print("core fraction per us (first 60):", " ".join(f"{x:.2f}" for x in fc[:60]))
 
 # average number of workgroups resident on the chip = sum of lifetimes / kernel span
 print(f"mean resident workgroups: {(wg_end - wg_start).sum() / (wg_end.max() - wg_start.min()):.1f}")
+first = wg_start.min()
+print("workgroups started within 5 / 20 us of the first:", int((wg_start < first + 500).sum()), int((wg_start < first + 2000).sum()))
+ev = np.concatenate([np.stack([wg_start, np.ones_like(wg_start)], 1), np.stack([wg_end, -np.ones_like(wg_end)], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+print("maximum number of concurrently resident workgroups:", int(np.cumsum(ev[:, 1]).max()))
