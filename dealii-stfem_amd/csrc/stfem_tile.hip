@@ -197,6 +197,11 @@ __device__ __forceinline__ void wait_vmcnt(int n)
   else wait_vmcnt_imm<0>();
 }
 
+// waves per SIMD the general-geometry kernel is compiled for (launch bounds)
+#ifndef STFEM_GEN_WAVES
+#define STFEM_GEN_WAVES 1
+#endif
+
 // dst rows are written once and not read again by this kernel
 #ifdef STFEM_NT_STORES
 #define STFEM_DST_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
@@ -770,8 +775,8 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
       hipLaunchKernelGGL((st_sweep_cart_tile<P, NBM, WW, AA, CC, GG, 0>), dim3(nblocks), dim3(TileGeom<P, NBM, GG>::NT), 0, st, prm, tp); \
   } while (0)
     if (prm.metric) { // general geometry / per-q coefficients (baked into the metric)
-      if (tp.add) STFEM_LAUNCH(1, true, false, true);
-      else STFEM_LAUNCH(1, false, false, true);
+      if (tp.add) STFEM_LAUNCH(STFEM_GEN_WAVES, true, false, true);
+      else STFEM_LAUNCH(STFEM_GEN_WAVES, false, false, true);
     } else if (tp.add && coef) STFEM_LAUNCH(WV, true, true, false);
     else if (tp.add) STFEM_LAUNCH(WV, true, false, false);
     else if (coef) STFEM_LAUNCH(WV, false, true, false);
@@ -794,7 +799,7 @@ template <int P, int NBM, int WV> int tile_occupancy_w(bool general)
   hipError_t e;
   const void *kern;
   if (general) {
-    auto k = st_sweep_cart_tile<P, NBM, 1, false, false, true, 0>;
+    auto k = st_sweep_cart_tile<P, NBM, STFEM_GEN_WAVES, false, false, true, 0>;
     kern = reinterpret_cast<const void *>(k);
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, TileGeom<P, NBM, true>::NT, 0);
   } else {
