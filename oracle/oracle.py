@@ -64,6 +64,9 @@ def lib():
         L.stfo_stokes_n_pressure.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.stfo_stokes_apply.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
+        # default thread count: the visible CPUs, but never more than 16 (a GPU box advertises 256
+        # logical CPUs and grants far fewer; oversubscribed libgomp threads spin)
+        L.stfo_set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
         _lib = L
     return _lib
 

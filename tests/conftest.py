@@ -18,6 +18,9 @@ def oracle_mod():
     """The CPU oracle (test infrastructure); builds oracle/libstfem_oracle.so on demand."""
     from oracle import oracle
     oracle.build()
+    # the GPU box shows 256 logical CPUs but grants a share of 16: libgomp's default (one thread per
+    # visible CPU, spinning) makes every small parallel loop of the oracle take seconds there
+    oracle.lib().stfo_set_threads(min(8, len(os.sched_getaffinity(0))))
     return oracle
 
 

@@ -343,3 +343,39 @@ def test_fp32_vs_oracle(case, stfem, oracle_mod):
     stfem.tensorproduct_add(ctx, a, np.array([[0.5]]), b)
     assert rel(a.download(), 1.5 * X[:1]) < 1e-6
     assert abs(stfem.dot(ctx, b, b) - np.sum(X[:1].astype(np.float32).astype(np.float64) ** 2)) < 1e-6 * np.sum(X[:1] ** 2)
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.integers(1, 5))
+    nc = tuple(int(v) for v in rng.integers(1, 16 if p <= 2 else 14, size=3))
+    tt = "CGP" if rng.random() < 0.6 else "DG"
+    r = int(rng.integers(1, 4)) if tt == "CGP" else int(rng.integers(0, 3))
+    ns = int(rng.integers(1, 3))
+    mask = int(rng.integers(0, 64))
+    up = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3))
+    pert = bool(rng.random() < 0.3)
+    coef = bool(rng.random() < 0.4)
+    return p, nc, up, mask, tt, r, ns, pert, coef
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_vs_oracle(seed, stfem, oracle_mod):
+    """Seeded random sweep over degree, ragged mesh sizes (tiles, chunks and cell groups that do not
+    divide the mesh), block counts, Dirichlet masks, anisotropic boxes, perturbed meshes and per-cell
+    coefficients: vmult and Tvmult against the oracle."""
+    p, nc, up, mask, tt, r, ns, pert, coef = _random_case(seed)
+    t = stfem.CGP if tt == "CGP" else stfem.DG
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(t, r, 0.05, ns)
+    verts = stfem.mesh_vertices(nc, (0, 0, 0), up, distort=0.12 if pert else 0.0, seed=seed)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts, dirichlet_mask=mask)
+    orc = oracle_mod.Oracle(p, nc, verts, mask)
+    if coef:
+        c = np.random.default_rng(seed).uniform(0.5, 3.0, ctx.n_cells)
+        ctx.evaluate_coefficient(c, which=1)
+        orc.set_coefficient(1, np.repeat(c, (p + 1) ** 3))
+    nb = Alpha.shape[0]
+    X = random_blocks(nb, ctx.n_dofs, seed=seed)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    assert rel(apply(stfem, ctx, Alpha, Beta, X, transpose=True),
+               orc.st_vmult(Alpha, Beta, X, transpose=True)) < TOL
