@@ -9,8 +9,9 @@ namespace stfem {
 constexpr int MAX_BLOCKS = 8; // temporal blocks handled by one launch (larger systems are tiled)
 constexpr int EO_N = 16;      // >= eo_size(5)
 
-// Workgroups per CU the fp64 tile kernel is launched for (launch bounds 2 or 3): two; three fit
-// for small degrees / few blocks but measured no faster.  STFEM_TILE_WAVES=2|3 overrides.
+// Waves per SIMD the fp64 tile kernel is compiled for (launch bounds): two.  The runtime keeps three
+// narrow-tile workgroups on a CU anyway when registers and LDS allow.  Builds with -DSTFEM_ALLOW_W3
+// also hold the 168-VGPR variants, selected with STFEM_TILE_WAVES=3 (experiments only).
 int tile_wg_per_cu(int p, int nbm);
 } // namespace stfem
 

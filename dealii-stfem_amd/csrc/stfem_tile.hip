@@ -147,7 +147,11 @@ __device__ __forceinline__ void load_plane(const real_t *__restrict__ s, int nx,
 // will not drain them (and, vmcnt being in-order, every store issued after them) with a
 // vmcnt(0) at the next use.  The caller waits with wait_vmcnt(n), n <= number of VMEM
 // instructions this wave has issued since, before touching PA.
-template <int P>
+// ASYNC = false falls back to ordinary loads: REQUIRED for every instantiation whose register
+// allocation spills, because the compiler would store a spilled destination register to scratch
+// right after the asm statement, i.e. before the load it does not know about has landed.  Only
+// the fp64 Cartesian kernels with up to three blocks (no spills, checked with tools/kinfo.sh) use it.
+template <int P, bool ASYNC>
 __device__ __forceinline__ void load_plane_async(const real_t *s, int nx, real_t (&PA)[(P + 1) * (P + 1)])
 {
   constexpr int N = P + 1;
@@ -155,6 +159,10 @@ __device__ __forceinline__ void load_plane_async(const real_t *s, int nx, real_t
   load_plane<P>(s, nx, PA); // fp32: ordinary (compiler-tracked) loads
   return;
 #else
+  if (!ASYNC) {
+    load_plane<P>(s, nx, PA);
+    return;
+  }
   typedef double d2 __attribute__((ext_vector_type(2)));
   STFEM_UNROLL
   for (int y = 0; y < N; ++y) {
@@ -217,6 +225,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
   using G = Geometry<P, NBM>;
   constexpr int N = TG::N;
   constexpr int NT = TG::NT, LPR = TG::LPR, RPI = TG::RPI, RPP = TG::RPP;
+  constexpr bool ASYNC_LOADS = !GEN && NBM <= 3; // see load_plane_async
   constexpr int TX = TG::TX, TY = TG::TY, PLANE = TG::PLANE;
   __shared__ real_t smem[TG::LDS_DOUBLES];
   real_t *acc = smem; // [blk][k][Y][X], aliases the transpose slabs
@@ -302,9 +311,9 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 
   real_t PA[SX][N * N];
   STFEM_UNROLL
-  for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA[h]);
+  for (int h = 0; h < SX; ++h) load_plane_async<P, ASYNC_LOADS>(src_lane[h] + plane_stride * (int64_t(P) * t.cz0), prm.nx, PA[h]);
 #ifndef STFEM_F32
-  wait_vmcnt_imm<0>();
+  if (ASYNC_LOADS) wait_vmcnt_imm<0>();
 #endif
 #ifdef STFEM_ABLATION
 #define STFEM_LAYER_BARRIER() do { if (!(ex & 2048)) __syncthreads(); } while (0)
@@ -395,7 +404,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     real_t PB[SX][N * N];
     if (!last_layer && !(ex & 1)) {
       STFEM_UNROLL
-      for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PB[h]);
+      for (int h = 0; h < SX; ++h) load_plane_async<P, ASYNC_LOADS>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PB[h]);
     }
 #endif
     STFEM_UNROLL
@@ -504,7 +513,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
 #else
     if (!last_layer && !(ex & 1)) {
       STFEM_UNROLL
-      for (int h = 0; h < SX; ++h) load_plane_async<P>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA[h]);
+      for (int h = 0; h < SX; ++h) load_plane_async<P, ASYNC_LOADS>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA[h]);
     }
 #endif
     STFEM_TL(6);
@@ -666,7 +675,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
       STFEM_UNROLL
       for (int o = 0; o < (TY + RPP - 1) / RPP; ++o) n_o += (RPI * wave_u + RPP * o < ymax) ? 1 : 0;
 #if !defined(STFEM_F32) && !defined(STFEM_EARLY_PREFETCH)
-      wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
+      if (ASYNC_LOADS) wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
 #else
       (void)n_o;
 #endif
@@ -828,7 +837,11 @@ template <int P, int NBM> int tile_occupancy_t(bool general)
   return tile_occupancy_w<P, NBM, 4>(general);
 #endif
 #else
+#ifdef STFEM_ALLOW_W3 // experiment builds only: the 168-VGPR variants spill for some (P, NBM), see load_plane_async
   return tile_wg_per_cu(P, NBM) == 3 ? tile_occupancy_w<P, NBM, 3>(general) : tile_occupancy_w<P, NBM, 2>(general);
+#else
+  return tile_occupancy_w<P, NBM, 2>(general);
+#endif
 #endif
 }
 
@@ -842,7 +855,11 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
   return launch_tile_w<P, NBM, 4>(prm, tp, st);
 #endif
 #else
+#ifdef STFEM_ALLOW_W3
   return tile_wg_per_cu(P, NBM) == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
+#else
+  return launch_tile_w<P, NBM, 2>(prm, tp, st);
+#endif
 #endif
 }
 

@@ -153,6 +153,9 @@ CASES = [
     (1, (9, 7, 5), (0, 0, 0), (1, 1, 1), 63, "DG", 0, 1, 0.2),             # nb=1, Q1
     (2, (4, 4, 3), (0, 0, 0), (1, 1, 1), 63, "CGP", 3, 4, 0.05),           # nb=12 -> tiled launches
     (1, (1, 1, 1), (0, 0, 0), (1, 1, 1), 0, "CGP", 1, 1, 1.0),             # single cell
+    (4, (5, 9, 3), (0, 0, 0), (1, 1, 1), 63, "CGP", 4, 2, 0.02),           # Q4, nb=8: the largest instantiation
+    (3, (9, 5, 7), (0, 0, 0), (1, 2, 1), 0b100110, "DG", 3, 2, 0.02),      # Q3, nb=8
+    (4, (13, 5, 9), (0, 0, 0), (1, 1, 1), 63, "DG", 2, 1, 0.02),           # Q4, nb=3 (two cell groups per wave)
 ]
 
 
