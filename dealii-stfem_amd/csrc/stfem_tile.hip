@@ -711,7 +711,8 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
   const int tid_y = id - tp.ntx, tid_z = id - tp.ntx * tp.nty, tid_yz = tid_z - tp.ntx;
   // top plane of the chunk below, in its own slab coordinates
   const int top_below = has_z ? P * (t.cz0 - chunk_begin(t.tc - 1, prm.ncz, tp.ntc)) : 0;
-  for (int j = 0; j < prm.nbo; ++j) {
+  { // one workgroup per (tile, output block): the blocks' dependent load -> store chains run side by side
+    const int j = blockIdx.y;
     real_t *d = prm.dst[j] + g0;
     const int64_t sy = tp.zp * tp.tX, sz = tp.tY * tp.tX;
     const real_t *yh_y = tp.yh + (int64_t(tid_y) * nbm + j) * sy;   // (tx, ty-1, tc)
@@ -721,7 +722,8 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
     const int64_t left_y = int64_t(nbm) * sy, left_z = int64_t(nbm) * sz;
     // four rows per thread in flight (the loop is a chain of dependent load -> add -> store otherwise)
     constexpr int U = 4;
-    if (has_y) // rows Y = 0, Z >= (has_z ? 1 : 0): contributions of the tiles below in y
+    // blockIdx.z splits the two independent parts (y-face rows / z-face plane) over two workgroups
+    if (has_y && blockIdx.z == 0) // rows Y = 0, Z >= (has_z ? 1 : 0): contributions of the tiles below in y
       for (int Z0 = rg + has_z; Z0 < Zn; Z0 += U * nrg) {
         real_t s[U], v[U];
         STFEM_UNROLL
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(256) void st_tile_fixup(const SweepParams prm, cons
           if (Z < Zn) d[plane_stride * Z] = v[u] + s[u];
         }
       }
-    if (has_z) // plane Z = 0: tiles below in z, and for its row Y = 0 also below in y
+    if (has_z && blockIdx.z == 1) // plane Z = 0: tiles below in z, and for its row Y = 0 also below in y
       for (int Y0 = rg; Y0 < Yn; Y0 += U * nrg) {
         real_t s[U], v[U];
         STFEM_UNROLL
@@ -794,7 +796,7 @@ template <int P, int NBM, int WV> int launch_tile_w(const SweepParams &prm, cons
     if (hipGetLastError() != hipSuccess) return -3;
   }
   if (tp.nty > 1 || tp.ntc > 1) {
-    hipLaunchKernelGGL((st_tile_fixup<P>), dim3(tp.ntx * tp.nty * tp.ntc), dim3(256), 0, st, prm, tp, NBM);
+    hipLaunchKernelGGL((st_tile_fixup<P>), dim3(tp.ntx * tp.nty * tp.ntc, prm.nbo, 2), dim3(256), 0, st, prm, tp, NBM);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   return 0;
