@@ -34,6 +34,10 @@ struct Prec64 {
     return v - 100;
   }
   static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f64::launch_cart_tile(p, s, pl, st); }
+  using PPlan = f64::PencilPlan;
+  static int pencil_geometry(int p, int nbm, int ty, PPlan &pl) { return f64::pencil_geometry(p, nbm, ty, pl); }
+  static int pencil(int p, const Sweep &s, const PPlan &pl, void *st) { return f64::launch_pencil(p, s, pl, st); }
+  static const char *pencil_name() { return "st_sweep_pencil<f64>"; }
   static int diagonal(const Diag &d, void *st) { return f64::launch_diagonal(d, st); }
   static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
                     int ll, const real *cm, int ml, real *m, void *st)
@@ -58,6 +62,10 @@ struct Prec32 {
     return v - 100;
   }
   static int tile(int p, const Sweep &s, const Plan &pl, void *st) { return f32::launch_cart_tile(p, s, pl, st); }
+  using PPlan = f32::PencilPlan;
+  static int pencil_geometry(int p, int nbm, int ty, PPlan &pl) { return f32::pencil_geometry(p, nbm, ty, pl); }
+  static int pencil(int p, const Sweep &s, const PPlan &pl, void *st) { return f32::launch_pencil(p, s, pl, st); }
+  static const char *pencil_name() { return "st_sweep_pencil<f32>"; }
   static int diagonal(const Diag &d, void *st) { return f32::launch_diagonal(d, st); }
   static int metric(int p, const int nc[3], const double *v, const double *xq, const double *wq, const real *cl,
                     int ll, const real *cm, int ml, real *m, void *st)
@@ -103,7 +111,12 @@ struct stfem_ctx {
   // tile variant: halo slabs (grown on demand)
   void *d_halo = nullptr;
   size_t halo_doubles = 0; // elements
-  int variant = 0; // 0 = tile (default), 1 = atomic
+  int variant = 0; // 0 = pencil (default; tile where the pencil kernel has no instantiation), 1 = atomic, 2 = tile
+  // tuning / experiment switches, read once at context creation (STFEM_* environment variables)
+  int env_tile_lz = 0, env_exp = 0, env_stagger = 0, env_stagger_div = 256, env_pencil_ty = 0, env_pencil_lz = 0;
+  const char *env_timeline = nullptr;
+  long long *d_timeline = nullptr; // diagnostic builds: phase timestamps of the last apply
+  size_t tl_n = 0;
   // general-geometry path: device copies of vertices and the 1D rule, metric terms per (cell, q)
   double *d_vertices = nullptr, *d_rule = nullptr;
   void *d_metric = nullptr;
@@ -224,7 +237,15 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
     c->cartesian = cart;
     c->vertices.assign(v, v + 3 * nv);
   }
-  if (const char *v = getenv("STFEM_VARIANT")) c->variant = std::string(v) == "atomic" ? 1 : 0;
+  if (const char *v = getenv("STFEM_VARIANT")) c->variant = std::string(v) == "atomic" ? 1 : (std::string(v) == "tile" ? 2 : 0);
+  auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+  c->env_tile_lz = env_int("STFEM_TILE_LZ", 0);
+  c->env_exp = env_int("STFEM_EXP", 0);
+  c->env_stagger = env_int("STFEM_STAGGER", 0);
+  c->env_stagger_div = std::max(1, env_int("STFEM_STAGGER_DIV", 256));
+  c->env_pencil_ty = env_int("STFEM_PENCIL_TY", 0);
+  c->env_pencil_lz = env_int("STFEM_PENCIL_LZ", 0);
+  c->env_timeline = getenv("STFEM_TIMELINE");
   if (hipMalloc(&c->d_scratch, 4096) != hipSuccess) {
     delete c;
     return STFEM_ERR_OUT_OF_MEMORY;
@@ -244,6 +265,7 @@ void stfem_ctx_destroy(stfem_ctx *c)
   if (c->d_vertices) (void)hipFree(c->d_vertices);
   if (c->d_rule) (void)hipFree(c->d_rule);
   if (c->d_metric) (void)hipFree(c->d_metric);
+  if (c->d_timeline) (void)hipFree(c->d_timeline);
   delete c;
 }
 
@@ -416,8 +438,8 @@ template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm,
   tp.nty = (c->nc[1] + tp.rows - 1) / tp.rows;
   const int ncz = c->nc[2];
   int ntc = 1;
-  if (const char *e = getenv("STFEM_TILE_LZ")) {
-    const int lz = std::max(1, std::min(ncz, atoi(e)));
+  if (c->env_tile_lz > 0) {
+    const int lz = std::max(1, std::min(ncz, c->env_tile_lz));
     ntc = (ncz + lz - 1) / lz;
   } else {
     (void)nbm;
@@ -434,6 +456,33 @@ template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm,
   tp.ntc = ntc;
   tp.lz = (ncz + ntc - 1) / ntc; // longest chunk
   tp.zp = c->p * tp.lz + 1;
+}
+
+// Chooses the decomposition of the pencil variant: pencils of cpw x ty cells, four of them stacked
+// in y per workgroup, z-chunks such that the last round of resident workgroups (two per CU) is full.
+template <class PL> static void plan_pencil(const stfem_ctx *c, PL &pp)
+{
+  pp.ntx = (c->nc[0] + pp.cpw - 1) / pp.cpw;
+  const int cyw = pp.ty * 4;
+  pp.ntyw = (c->nc[1] + cyw - 1) / cyw;
+  const int ncz = c->nc[2];
+  int ntc = 1;
+  if (c->env_pencil_lz > 0) {
+    const int lz = std::max(1, std::min(ncz, c->env_pencil_lz));
+    ntc = (ncz + lz - 1) / lz;
+  } else {
+    const int64_t slots = int64_t(c->n_cu > 0 ? c->n_cu : 256) * 2;
+    const int64_t columns = int64_t((pp.ntx + 1) / 2) * pp.ntyw; // of the larger colour
+    double best = 1e300;
+    for (int n = 1; n <= ncz; ++n) {
+      const int64_t rounds = (columns * n + slots - 1) / slots;
+      const double cost = double(rounds) * ((ncz + n - 1) / n + 0.5) * (1.0 + 1e-3 * n);
+      if (cost < best) { best = cost; ntc = n; }
+    }
+  }
+  pp.ntc = ntc;
+  pp.lz = (ncz + ntc - 1) / ntc;
+  pp.zp = c->p * pp.lz + 1;
 }
 
 // (Re)builds the per-quadrature-point metric of the general path.  The coefficients in force
@@ -508,7 +557,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
     prm.metric = static_cast<const real *>(c->d_metric);
     prm.vol = real(1); // detJ and the weights live in the metric
   }
-  prm.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
+  prm.experiment = c->env_exp;
   for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS) {
     bool first = true; // first launch into this row panel overwrites dst unless add
     for (int i0 = 0; i0 < nbi; i0 += MAX_BLOCKS) {
@@ -529,9 +578,59 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
       for (int j = 0; j < tj; ++j) prm.dst[j] = static_cast<real *>(dst->blk[j0 + j]);
       for (int i = 0; i < ti; ++i) prm.src[i] = static_cast<const real *>(src->blk[i0 + i]);
       int rc;
+      typename PR::PPlan pp;
+      std::memset(&pp, 0, sizeof(pp));
+      const int pencil_ty = c->env_pencil_ty > 0 ? c->env_pencil_ty : 2;
       if (atomic) {
         rc = PR::atomic(c->p, prm, st);
         c->last_kernel = PR::atomic_name();
+      } else if (c->variant == 0 && !general && PR::pencil_geometry(c->p, std::max(tj, ti), pencil_ty, pp) == 0) {
+        plan_pencil(c, pp);
+        const int nbm = std::max(tj, ti);
+        const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
+        const int n1 = c->p + 1, xs = n1 + (n1 & 1);
+        const size_t ntiles = size_t(pp.ntx) * pp.ntyw * pp.ntc;
+        const size_t nyh = ntiles * nbm_r * pp.zp * pp.tX, nzh = ntiles * nbm_r * pp.tYW * pp.tX,
+                     nxs = size_t(pp.ntc) * (pp.ntyw * 4) * pp.ntx * nbm_r * pp.lz * pp.ty * n1 * xs;
+        if (nyh + nzh + 2 * nxs > c->halo_doubles) {
+          HIP_TRY(hipStreamSynchronize(st));
+          if (c->d_halo) HIP_TRY(hipFree(c->d_halo));
+          c->d_halo = nullptr;
+          c->halo_doubles = 0;
+          if (hipMalloc(&c->d_halo, (nyh + nzh + 2 * nxs) * sizeof(real)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+          c->halo_doubles = nyh + nzh + 2 * nxs;
+        }
+        pp.yh = static_cast<real *>(c->d_halo);
+        pp.zh = pp.yh + nyh;
+        pp.xl = pp.zh + nzh;
+        pp.xr = pp.xl + nxs;
+        pp.add = (add || !first) ? 1 : 0;
+        // diagnostic builds only (tools/build_pencil_exp.sh -DSTFEM_PENCIL_TIMELINE): phase timestamps of
+        // the even-colour launch, dumped to the file named by STFEM_TIMELINE after every apply
+        const size_t ptl_n = ntiles * 4 * pp.lz * pp.ty * 8;
+        if (c->env_timeline) {
+          if (c->tl_n < ptl_n) {
+            if (c->d_timeline) HIP_TRY(hipFree(c->d_timeline));
+            c->d_timeline = nullptr;
+            if (hipMalloc(&c->d_timeline, ptl_n * sizeof(long long)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+            c->tl_n = ptl_n;
+          }
+          HIP_TRY(hipMemsetAsync(c->d_timeline, 0, ptl_n * sizeof(long long), st));
+          pp.timeline = c->d_timeline;
+        }
+        rc = PR::pencil(c->p, prm, pp, st);
+        c->last_kernel = PR::pencil_name();
+        if (c->env_timeline && rc == 0) {
+          HIP_TRY(hipStreamSynchronize(st));
+          std::vector<long long> h(ptl_n);
+          HIP_TRY(hipMemcpy(h.data(), c->d_timeline, ptl_n * sizeof(long long), hipMemcpyDeviceToHost));
+          if (FILE *f = fopen(c->env_timeline, "wb")) {
+            const long long hdr[4] = {(long long)ntiles, 4, (long long)pp.lz * pp.ty, 8};
+            fwrite(hdr, sizeof(long long), 4, f);
+            fwrite(h.data(), sizeof(long long), ptl_n, f);
+            fclose(f);
+          }
+        }
       } else {
         typename PR::Plan tp;
         std::memset(&tp, 0, sizeof(tp));
@@ -556,19 +655,24 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         tp.xl = tp.zh + nzh;
         tp.xr = tp.xl + nxs;
         tp.add = (add || !first) ? 1 : 0;
-        tp.experiment = getenv("STFEM_EXP") ? atoi(getenv("STFEM_EXP")) : 0;
-        tp.stagger = getenv("STFEM_STAGGER") ? atoi(getenv("STFEM_STAGGER")) : 0;
-        tp.stagger_div = getenv("STFEM_STAGGER_DIV") ? std::max(1, atoi(getenv("STFEM_STAGGER_DIV"))) : 256;
+        tp.experiment = c->env_exp;
+        tp.stagger = c->env_stagger;
+        tp.stagger_div = c->env_stagger_div;
         // diagnostic builds only (tools/build_abl.sh -DSTFEM_TIMELINE): phase timestamps of the
         // even-colour launch, dumped to the file named by STFEM_TIMELINE after every apply
-        static long long *tl_dev = nullptr;
-        const char *tl_path = getenv("STFEM_TIMELINE");
+        const char *tl_path = c->env_timeline;
         const size_t tl_n = size_t(tp.ntx) * tp.nty * tp.ntc * 4 * tp.wx * tp.lz * 16;
         if (tl_path) {
-          if (!tl_dev && hipMalloc(&tl_dev, tl_n * sizeof(long long)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
-          HIP_TRY(hipMemsetAsync(tl_dev, 0, tl_n * sizeof(long long), st));
-          tp.timeline = tl_dev;
+          if (c->tl_n < tl_n) {
+            if (c->d_timeline) HIP_TRY(hipFree(c->d_timeline));
+            c->d_timeline = nullptr;
+            if (hipMalloc(&c->d_timeline, tl_n * sizeof(long long)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+            c->tl_n = tl_n;
+          }
+          HIP_TRY(hipMemsetAsync(c->d_timeline, 0, tl_n * sizeof(long long), st));
+          tp.timeline = c->d_timeline;
         }
+        long long *tl_dev = c->d_timeline;
         rc = PR::tile(c->p, prm, tp, st);
         c->last_kernel = PR::tile_name();
         if (tl_path && rc == 0) {

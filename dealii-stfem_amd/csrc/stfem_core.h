@@ -356,6 +356,144 @@ cell_core_general(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_
   wave_lds_fence();
 }
 
+// "Pencil" form of cell_core (stfem_pencil.hip): the lanes of a cell-block run along the MEMORY x
+// direction (lane = x-node i, registers [y][z]), so that the gather and the scatter of
+// do_cell_integral_range (operators.h:1112-1133) are rows of contiguous doubles across the lanes
+// and the z / y faces shared with the next cell of a marching wave stay in the lane's own
+// registers.  The algorithm is the fast diagonalisation of cell_core with the roles of x and z
+// exchanged; the three phases are separate functions so that the caller can issue the next
+// cell group's src loads between them.
+//   forward : nodal [y][z] -> modal in z, y -> LDS (plane of lane i)
+//   middle  : lane k = z-mode; per y-mode row: read the x-lines of all input blocks, to modal
+//             space in x, diagonal scaling + temporal combination, back to nodal values in x,
+//             written straight back to the slab.  The x = P node of a cell IS the x = 0 node of
+//             the next cell of the wave: its partial sum is added into the neighbour's slot
+//             (ds_add_f64 after the neighbour's own write; LDS operations of one wave execute in
+//             order), which resolves the x faces inside a wave without any shuffle.  The two
+//             faces at the ends of the wave's cell row travel in this (y-mode, z-mode) form:
+//             xin is added to them, xout returns them.
+//   backward: plane of lane i <- LDS, modal -> nodal in y, z.
+template <int P, int NBM> struct PencilCore {
+  using G = Geometry<P, NBM>;
+  static constexpr int N = G::N, NN = N * N, CBS = G::CBS;
+
+  static __device__ __forceinline__ void forward(const SweepParams &prm, real_t *__restrict__ cb_lds, int k,
+                                                 bool in_active, real_t (&PA)[NN])
+  {
+    fd_plane<N, true, true>(prm.fd_W, PA);
+    fd_plane<N, true, false>(prm.fd_W, PA);
+    if (in_active) {
+      STFEM_UNROLL
+      for (int y = 0; y < N; ++y)
+        STFEM_UNROLL
+      for (int x = 0; x < N; ++x) cb_lds[k * NN + y * N + x] = PA[y * N + x];
+    }
+    wave_lds_fence();
+  }
+
+  // add_lo / add_hi: this lane's cell is the first / last of the row and receives xin on that face;
+  // is_first / is_last select what xout returns (DIVERT) and who keeps its own x = P slot.
+  template <bool COLLECT, bool DIVERT>
+  static __device__ __forceinline__ void middle(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave,
+                                                int blk, int k, bool out_active, bool is_first, bool is_last,
+                                                bool add_lo, bool add_hi, real_t lzk, const real_t (&aK)[NBM],
+                                                const real_t (&aM)[NBM], const real_t (&xin)[N], real_t (&xout)[N])
+  {
+    // lzk: eigenvalue of this lane's z-mode (lane-constant: the caller keeps it; selecting it here
+    // becomes an indexed global load from the kernel arguments inside the cell loop)
+    real_t *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+    // opaque copies: see cell_core
+    real_t wK[NBM], wM[NBM];
+    STFEM_UNROLL
+    for (int i = 0; i < NBM; ++i) {
+      wK[i] = aK[i];
+      wM[i] = aM[i];
+      asm volatile("" : "+v"(wK[i]), "+v"(wM[i]));
+    }
+    asm volatile("" : "+v"(lzk));
+    real_t vbuf[2][NBM][N];
+    auto load_row = [&](int y, real_t (&v)[NBM][N]) {
+      int base = cell_in_wave * NBM * CBS + y * N + k;
+      asm volatile("" : "+v"(base));
+      STFEM_UNROLL
+      for (int i = 0; i < NBM; ++i)
+        if (i == 0 || i < prm.nbi) {
+          STFEM_UNROLL
+          for (int x = 0; x < N; ++x) v[i][x] = lds[base + i * CBS + x * NN];
+        }
+    };
+    load_row(0, vbuf[0]);
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y) {
+      if (y + 1 < N) load_row(y + 1, vbuf[(y + 1) & 1]);
+      const real_t sy = lzk + prm.fd_ly[y];
+      real_t acc[N];
+      if (NBM <= 2) {
+        STFEM_UNROLL
+        for (int i = 0; i < NBM; ++i) {
+          if (i == 0 || i < prm.nbi) {
+            real_t t[N];
+            fd_forward<N>(prm.fd_W, vbuf[y & 1][i], t);
+            STFEM_UNROLL
+            for (int x = 0; x < N; ++x) {
+              const real_t d = fma(wK[i], sy + prm.fd_lx[x], wM[i]);
+              acc[x] = i == 0 ? d * t[x] : fma(d, t[x], acc[x]);
+            }
+          }
+        }
+      } else {
+        real_t ua[N], ub[N];
+        STFEM_UNROLL
+        for (int x = 0; x < N; ++x) ua[x] = ub[x] = real_t(0);
+        STFEM_UNROLL
+        for (int i = 0; i < NBM; ++i) {
+          if (i < prm.nbi) {
+            STFEM_UNROLL
+            for (int x = 0; x < N; ++x) {
+              ua[x] = fma(wK[i], vbuf[y & 1][i][x], ua[x]);
+              ub[x] = fma(wM[i], vbuf[y & 1][i][x], ub[x]);
+            }
+          }
+        }
+        real_t ta[N], tb[N];
+        fd_forward<N>(prm.fd_W, ua, ta);
+        fd_forward<N>(prm.fd_W, ub, tb);
+        STFEM_UNROLL
+        for (int x = 0; x < N; ++x) acc[x] = fma(sy + prm.fd_lx[x], ta[x], tb[x]);
+      }
+      real_t r[N];
+      fd_backward<N>(prm.fd_W, acc, r);
+      if (COLLECT) {
+        r[0] += add_lo ? xin[y] : real_t(0);
+        r[P] += add_hi ? xin[y] : real_t(0);
+      }
+      if (DIVERT) xout[y] = is_first ? r[0] : r[P];
+      pin(r);
+      if (out_active) {
+        STFEM_UNROLL
+        for (int x = 0; x < P; ++x) cb_lds[x * NN + y * N + k] = r[x];
+        asm volatile("" ::: "memory"); // the neighbour's own x = 0 write precedes the add below
+        if (is_last) cb_lds[P * NN + y * N + k] = r[P];
+        else atomicAdd(&cb_lds[NBM * CBS + y * N + k], r[P]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+  }
+
+  static __device__ __forceinline__ void backward(const SweepParams &prm, const real_t *__restrict__ cb_lds, int k,
+                                                  real_t (&OUT)[NN])
+  {
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y)
+      STFEM_UNROLL
+    for (int x = 0; x < N; ++x) OUT[y * N + x] = cb_lds[k * NN + y * N + x];
+    fd_plane<N, false, false>(prm.fd_W, OUT);
+    fd_plane<N, false, true>(prm.fd_W, OUT);
+    wave_lds_fence();
+  }
+};
+
 // Dirichlet flags of the plane (cell, k): which local rows/columns are constrained.
 struct PlaneMask {
   bool x0, x1, y0, y1, all;

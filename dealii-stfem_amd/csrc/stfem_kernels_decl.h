@@ -52,6 +52,24 @@ struct TilePlan {
   long long *timeline; // diagnostic builds (-DSTFEM_TIMELINE): [block][wave][layer][16] timestamps
 };
 
+// Decomposition used by the "pencil" variant (stfem_pencil.hip): every wave owns cpw x ty cells in
+// x-y and marches through the lz layers of a z-chunk; four waves stacked in y form a workgroup
+// tile.  x-neighbouring pencils are launched in two colours (odd pencils leave their end faces in
+// the x-slabs), partial sums on a workgroup tile's upper y / z faces go to halo slabs and are added
+// to their owner by st_pencil_fixup.
+struct PencilPlan {
+  int cpw, ty;        // cells per wave in x, cell rows per wave in y
+  int ntx, ntyw, ntc; // pencils in x, workgroup tiles in y, chunks in z
+  int lz;             // cell layers per chunk (longest)
+  int tX, tYW, zp;    // slab extents: P*cpw+1, P*ty*4+1, P*lz+1
+  real_t *yh, *zh;    // halo slabs: yh[tile][block][zl][X], zh[tile][block][Y][X]
+  real_t *xl, *xr;    // x-face slabs of odd pencils: [chunk][pencil row][tx][block][layer][cyl][k][N+1 padded]
+  int add;            // accumulate into dst instead of overwriting
+  long long *timeline; // diagnostic builds (-DSTFEM_PENCIL_TIMELINE): [block][wave][layer][cyl][8] timestamps
+};
+int pencil_geometry(int p, int nbm, int ty, PencilPlan &plan);
+int launch_pencil(int p, const SweepParams &prm, const PencilPlan &plan, void *stream);
+
 // Cartesian (axis-aligned uniform box) meshes, per-cell-constant coefficients.
 // Variant "atomic": result scattered with global fp64 atomics into a pre-zeroed dst.
 // Returns 0, or -2 if (p, nbm) has no instantiation.
