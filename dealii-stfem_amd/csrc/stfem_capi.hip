@@ -115,6 +115,7 @@ struct stfem_ctx {
   // tuning / experiment switches, read once at context creation (STFEM_* environment variables)
   int env_tile_lz = 0, env_exp = 0, env_stagger = 0, env_stagger_div = 256, env_pencil_ty = 0, env_pencil_lz = 0;
   const char *env_timeline = nullptr;
+  int *d_work = nullptr;           // pencil variant: tile counters
   long long *d_timeline = nullptr; // diagnostic builds: phase timestamps of the last apply
   size_t tl_n = 0;
   // general-geometry path: device copies of vertices and the 1D rule, metric terms per (cell, q)
@@ -266,6 +267,7 @@ void stfem_ctx_destroy(stfem_ctx *c)
   if (c->d_rule) (void)hipFree(c->d_rule);
   if (c->d_metric) (void)hipFree(c->d_metric);
   if (c->d_timeline) (void)hipFree(c->d_timeline);
+  if (c->d_work) (void)hipFree(c->d_work);
   delete c;
 }
 
@@ -462,7 +464,7 @@ template <class PL> static void plan_chunks(const stfem_ctx *c, PL &tp, int nbm,
 // in y per workgroup, z-chunks such that the last round of resident workgroups (two per CU) is full.
 template <class PL> static void plan_pencil(const stfem_ctx *c, PL &pp)
 {
-  pp.ntx = (c->nc[0] + pp.cpw - 1) / pp.cpw;
+  pp.ntx = (c->nc[0] + pp.cpw - 2) / (pp.cpw - 1); // cpw - 1 owned cells per pencil
   const int cyw = pp.ty * 4;
   pp.ntyw = (c->nc[1] + cyw - 1) / cyw;
   const int ncz = c->nc[2];
@@ -471,14 +473,12 @@ template <class PL> static void plan_pencil(const stfem_ctx *c, PL &pp)
     const int lz = std::max(1, std::min(ncz, c->env_pencil_lz));
     ntc = (ncz + lz - 1) / lz;
   } else {
+    // tiles are pulled at run time, so the last round need not be full: chunks of about 8 layers (z-halo
+    // 1/32 of the planes), but at least 3 tiles per resident workgroup so that the tail stays short
     const int64_t slots = int64_t(c->n_cu > 0 ? c->n_cu : 256) * 2;
-    const int64_t columns = int64_t((pp.ntx + 1) / 2) * pp.ntyw; // of the larger colour
-    double best = 1e300;
-    for (int n = 1; n <= ncz; ++n) {
-      const int64_t rounds = (columns * n + slots - 1) / slots;
-      const double cost = double(rounds) * ((ncz + n - 1) / n + 0.5) * (1.0 + 1e-3 * n);
-      if (cost < best) { best = cost; ntc = n; }
-    }
+    const int64_t columns = int64_t(pp.ntx) * pp.ntyw;
+    ntc = std::max(1, (ncz + 7) / 8);
+    while (ntc < ncz && columns * ntc < 3 * slots && (ncz + ntc) / (ntc + 1) >= 4) ++ntc;
   }
   pp.ntc = ntc;
   pp.lz = (ncz + ntc - 1) / ntc;
@@ -588,23 +588,22 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         plan_pencil(c, pp);
         const int nbm = std::max(tj, ti);
         const int nbm_r = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
-        const int n1 = c->p + 1, xs = n1 + (n1 & 1);
         const size_t ntiles = size_t(pp.ntx) * pp.ntyw * pp.ntc;
-        const size_t nyh = ntiles * nbm_r * pp.zp * pp.tX, nzh = ntiles * nbm_r * pp.tYW * pp.tX,
-                     nxs = size_t(pp.ntc) * (pp.ntyw * 4) * pp.ntx * nbm_r * pp.lz * pp.ty * n1 * xs;
-        if (nyh + nzh + 2 * nxs > c->halo_doubles) {
+        const size_t nyh = ntiles * nbm_r * pp.zp * pp.tX, nzh = ntiles * nbm_r * pp.tYW * pp.tX;
+        if (nyh + nzh > c->halo_doubles) {
           HIP_TRY(hipStreamSynchronize(st));
           if (c->d_halo) HIP_TRY(hipFree(c->d_halo));
           c->d_halo = nullptr;
           c->halo_doubles = 0;
-          if (hipMalloc(&c->d_halo, (nyh + nzh + 2 * nxs) * sizeof(real)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
-          c->halo_doubles = nyh + nzh + 2 * nxs;
+          if (hipMalloc(&c->d_halo, (nyh + nzh) * sizeof(real)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+          c->halo_doubles = nyh + nzh;
         }
         pp.yh = static_cast<real *>(c->d_halo);
         pp.zh = pp.yh + nyh;
-        pp.xl = pp.zh + nzh;
-        pp.xr = pp.xl + nxs;
         pp.add = (add || !first) ? 1 : 0;
+        if (!c->d_work && hipMalloc(&c->d_work, 8 * 32 * sizeof(int)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+        pp.work = c->d_work;
+        pp.grid = 2 * (c->n_cu > 0 ? c->n_cu : 256); // two 4-wave workgroups per CU (registers, LDS)
         // diagnostic builds only (tools/build_pencil_exp.sh -DSTFEM_PENCIL_TIMELINE): phase timestamps of
         // the even-colour launch, dumped to the file named by STFEM_TIMELINE after every apply
         const size_t ptl_n = ntiles * 4 * pp.lz * pp.ty * 8;

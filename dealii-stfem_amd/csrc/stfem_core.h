@@ -369,39 +369,53 @@ cell_core_general(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_
 //             written straight back to the slab.  The x = P node of a cell IS the x = 0 node of
 //             the next cell of the wave: its partial sum is added into the neighbour's slot
 //             (ds_add_f64 after the neighbour's own write; LDS operations of one wave execute in
-//             order), which resolves the x faces inside a wave without any shuffle.  The two
-//             faces at the ends of the wave's cell row travel in this (y-mode, z-mode) form:
-//             xin is added to them, xout returns them.
+//             order), which resolves the x faces inside a wave without any shuffle.
 //   backward: plane of lane i <- LDS, modal -> nodal in y, z.
 template <int P, int NBM> struct PencilCore {
   using G = Geometry<P, NBM>;
-  static constexpr int N = G::N, NN = N * N, CBS = G::CBS;
+  static constexpr int N = G::N, NN = N * N, CPW = G::CELLS_PER_WAVE;
+  // Slab layout: cell-block (cell c, block b) at (b * CPW + c) * CBS, element (plane, row, col) at
+  // plane * PS + row * N + col.  PS = 1 mod 16 doubles and CBS = N * PS make all four access
+  // patterns of the core free of LDS bank conflicts for 8-byte elements (the lanes of a cell-block
+  // step by PS doubles = 2 banks mod 32 in the plane-wise accesses and by one double in the
+  // middle phase, consecutive cell-blocks continue where the previous one ends: tools/lds_conflicts.py);
+  // with the dense strides 25 / 125 of Q4 nearly half of the LDS cycles were conflicts.
+  static constexpr int PS = 16 * ((NN - 1 + 15) / 16) + 1;
+  static constexpr int CBS = N * PS;
+  static constexpr int LDS_PER_WAVE = CPW * NBM * CBS;
+  static __device__ __forceinline__ int cb_offset(int cell, int blk) { return (blk * CPW + cell) * CBS; }
 
   static __device__ __forceinline__ void forward(const SweepParams &prm, real_t *__restrict__ cb_lds, int k,
                                                  bool in_active, real_t (&PA)[NN])
   {
-    fd_plane<N, true, true>(prm.fd_W, PA);
-    fd_plane<N, true, false>(prm.fd_W, PA);
+    // (tables re-read from the kernel arguments at the start of every phase, see opaque_zero(): held
+    // across the whole cell loop they cost ~50 SGPRs and push the loop's masks and offsets into VGPR lanes)
+    const real_t *W = prm.fd_W + opaque_zero();
+    fd_plane<N, true, true>(W, PA);
+    fd_plane<N, true, false>(W, PA);
     if (in_active) {
       STFEM_UNROLL
       for (int y = 0; y < N; ++y)
         STFEM_UNROLL
-      for (int x = 0; x < N; ++x) cb_lds[k * NN + y * N + x] = PA[y * N + x];
+      for (int x = 0; x < N; ++x) cb_lds[k * PS + y * N + x] = PA[y * N + x];
     }
     wave_lds_fence();
   }
 
-  // add_lo / add_hi: this lane's cell is the first / last of the row and receives xin on that face;
-  // is_first / is_last select what xout returns (DIVERT) and who keeps its own x = P slot.
-  template <bool COLLECT, bool DIVERT>
+  // is_last: this lane's cell is the last of the row and keeps its own x = P slot.
+  // lzk: eigenvalue of this lane's z-mode (lane-constant: the caller keeps it; selecting it here
+  // becomes an indexed global load from the kernel arguments inside the cell loop)
+  // row_hook(y) runs before row y is computed: the caller spreads its vector-memory instructions
+  // over the phase instead of issuing them in one burst (which fills the CU's memory pipeline and
+  // stalls the wave at the issue of every further one).
+  template <class Hook>
   static __device__ __forceinline__ void middle(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave,
-                                                int blk, int k, bool out_active, bool is_first, bool is_last,
-                                                bool add_lo, bool add_hi, real_t lzk, const real_t (&aK)[NBM],
-                                                const real_t (&aM)[NBM], const real_t (&xin)[N], real_t (&xout)[N])
+                                                int blk, int k, bool out_active, bool is_last, real_t lzk,
+                                                const real_t (&aK)[NBM], const real_t (&aM)[NBM], Hook &&row_hook)
   {
-    // lzk: eigenvalue of this lane's z-mode (lane-constant: the caller keeps it; selecting it here
-    // becomes an indexed global load from the kernel arguments inside the cell loop)
-    real_t *cb_lds = lds + (cell_in_wave * NBM + blk) * CBS;
+    real_t *cb_lds = lds + cb_offset(cell_in_wave, blk);
+    const int oz = opaque_zero();
+    const real_t *W = prm.fd_W + oz, *lx = prm.fd_lx + oz, *ly = prm.fd_ly + oz;
     // opaque copies: see cell_core
     real_t wK[NBM], wM[NBM];
     STFEM_UNROLL
@@ -413,30 +427,31 @@ template <int P, int NBM> struct PencilCore {
     asm volatile("" : "+v"(lzk));
     real_t vbuf[2][NBM][N];
     auto load_row = [&](int y, real_t (&v)[NBM][N]) {
-      int base = cell_in_wave * NBM * CBS + y * N + k;
+      int base = cb_offset(cell_in_wave, 0) + y * N + k;
       asm volatile("" : "+v"(base));
       STFEM_UNROLL
       for (int i = 0; i < NBM; ++i)
         if (i == 0 || i < prm.nbi) {
           STFEM_UNROLL
-          for (int x = 0; x < N; ++x) v[i][x] = lds[base + i * CBS + x * NN];
+          for (int x = 0; x < N; ++x) v[i][x] = lds[base + i * CPW * CBS + x * PS];
         }
     };
     load_row(0, vbuf[0]);
     STFEM_UNROLL
     for (int y = 0; y < N; ++y) {
+      row_hook(y);
       if (y + 1 < N) load_row(y + 1, vbuf[(y + 1) & 1]);
-      const real_t sy = lzk + prm.fd_ly[y];
+      const real_t sy = lzk + ly[y];
       real_t acc[N];
       if (NBM <= 2) {
         STFEM_UNROLL
         for (int i = 0; i < NBM; ++i) {
           if (i == 0 || i < prm.nbi) {
             real_t t[N];
-            fd_forward<N>(prm.fd_W, vbuf[y & 1][i], t);
+            fd_forward<N>(W, vbuf[y & 1][i], t);
             STFEM_UNROLL
             for (int x = 0; x < N; ++x) {
-              const real_t d = fma(wK[i], sy + prm.fd_lx[x], wM[i]);
+              const real_t d = fma(wK[i], sy + lx[x], wM[i]);
               acc[x] = i == 0 ? d * t[x] : fma(d, t[x], acc[x]);
             }
           }
@@ -456,41 +471,49 @@ template <int P, int NBM> struct PencilCore {
           }
         }
         real_t ta[N], tb[N];
-        fd_forward<N>(prm.fd_W, ua, ta);
-        fd_forward<N>(prm.fd_W, ub, tb);
+        fd_forward<N>(W, ua, ta);
+        fd_forward<N>(W, ub, tb);
         STFEM_UNROLL
-        for (int x = 0; x < N; ++x) acc[x] = fma(sy + prm.fd_lx[x], ta[x], tb[x]);
+        for (int x = 0; x < N; ++x) acc[x] = fma(sy + lx[x], ta[x], tb[x]);
       }
       real_t r[N];
-      fd_backward<N>(prm.fd_W, acc, r);
-      if (COLLECT) {
-        r[0] += add_lo ? xin[y] : real_t(0);
-        r[P] += add_hi ? xin[y] : real_t(0);
-      }
-      if (DIVERT) xout[y] = is_first ? r[0] : r[P];
+      fd_backward<N>(W, acc, r);
       pin(r);
       if (out_active) {
         STFEM_UNROLL
-        for (int x = 0; x < P; ++x) cb_lds[x * NN + y * N + k] = r[x];
+        for (int x = 0; x < P; ++x) cb_lds[x * PS + y * N + k] = r[x];
         asm volatile("" ::: "memory"); // the neighbour's own x = 0 write precedes the add below
-        if (is_last) cb_lds[P * NN + y * N + k] = r[P];
-        else atomicAdd(&cb_lds[NBM * CBS + y * N + k], r[P]);
+        if (is_last) cb_lds[P * PS + y * N + k] = r[P];
+        else atomicAdd(&cb_lds[CBS + y * N + k], r[P]); // the next cell of the row, same block
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
   }
 
+  // plane of lane i <- LDS, modal -> nodal in y (all columns), then row by row in z;
+  // row_done(y, r) receives the finished row y of the result plane, r[z], as soon as it is complete
+  template <class RowDone>
   static __device__ __forceinline__ void backward(const SweepParams &prm, const real_t *__restrict__ cb_lds, int k,
-                                                  real_t (&OUT)[NN])
+                                                  RowDone &&row_done)
   {
+    const real_t *W = prm.fd_W + opaque_zero();
+    real_t R[NN];
     STFEM_UNROLL
     for (int y = 0; y < N; ++y)
       STFEM_UNROLL
-    for (int x = 0; x < N; ++x) OUT[y * N + x] = cb_lds[k * NN + y * N + x];
-    fd_plane<N, false, false>(prm.fd_W, OUT);
-    fd_plane<N, false, true>(prm.fd_W, OUT);
+    for (int x = 0; x < N; ++x) R[y * N + x] = cb_lds[k * PS + y * N + x];
+    fd_plane<N, false, false>(W, R);
     wave_lds_fence();
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y) {
+      real_t x[N], r[N];
+      STFEM_UNROLL
+      for (int z = 0; z < N; ++z) x[z] = R[y * N + z];
+      fd_backward<N>(W, x, r);
+      row_done(y, r);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 };
 

@@ -52,19 +52,20 @@ struct TilePlan {
   long long *timeline; // diagnostic builds (-DSTFEM_TIMELINE): [block][wave][layer][16] timestamps
 };
 
-// Decomposition used by the "pencil" variant (stfem_pencil.hip): every wave owns cpw x ty cells in
-// x-y and marches through the lz layers of a z-chunk; four waves stacked in y form a workgroup
-// tile.  x-neighbouring pencils are launched in two colours (odd pencils leave their end faces in
-// the x-slabs), partial sums on a workgroup tile's upper y / z faces go to halo slabs and are added
-// to their owner by st_pencil_fixup.
+// Decomposition used by the "pencil" variant (stfem_pencil.hip): every wave owns cpw - 1 cells in x
+// (plus the halo slot: its left neighbour's last cell, computed once more) times ty cells in y and
+// marches through the lz layers of a z-chunk; four waves stacked in y form a workgroup tile.  All
+// pencils run in one launch; partial sums on a workgroup tile's upper y / z faces go to halo slabs
+// and are added to their owner by st_pencil_fixup.
 struct PencilPlan {
-  int cpw, ty;        // cells per wave in x, cell rows per wave in y
+  int cpw, ty;        // cell slots per wave in x (cpw - 1 owned + the halo slot), cell rows per wave in y
   int ntx, ntyw, ntc; // pencils in x, workgroup tiles in y, chunks in z
   int lz;             // cell layers per chunk (longest)
   int tX, tYW, zp;    // slab extents: P*cpw+1, P*ty*4+1, P*lz+1
   real_t *yh, *zh;    // halo slabs: yh[tile][block][zl][X], zh[tile][block][Y][X]
-  real_t *xl, *xr;    // x-face slabs of odd pencils: [chunk][pencil row][tx][block][layer][cyl][k][N+1 padded]
   int add;            // accumulate into dst instead of overwriting
+  int *work;          // tile counters, one per XCD (32 ints apart), zeroed before every launch
+  int grid;           // workgroups to launch: what the device keeps resident (they pull tiles until none is left)
   long long *timeline; // diagnostic builds (-DSTFEM_PENCIL_TIMELINE): [block][wave][layer][cyl][8] timestamps
 };
 int pencil_geometry(int p, int nbm, int ty, PencilPlan &plan);

@@ -20,10 +20,13 @@
 //      wave w+1 keeps its own part of that row back for one layer (4 registers), adds the two
 //      after the layer barrier and stores the complete row: one barrier per layer, and only to
 //      hand over rows - nobody waits for a phase of another wave;
-//   x: pencils are 2-coloured by the parity of their x index; odd pencils run first and leave
-//      the partial sums of their two end faces in x-slabs, in the (y-mode, z-mode) form they have
-//      in the middle of the core (N*N values per cell face); even pencils add them there and
-//      store complete rows;
+//   x: every pencil but the first of a row computes the last cell of its left neighbour once more
+//      (cell slot 0, the "halo slot": CPW - 1 owned cells per pencil) and so has that cell's
+//      contribution to its own x = 0 column without any exchange.  All pencils are independent and
+//      run in ONE launch; x-neighbouring pencils have neighbouring block numbers, run at the same
+//      time on one XCD and complete each other's cache lines in L2.  (Two colour launches with the
+//      faces handed over through slabs - the round-1 scheme - leave every other 200-byte piece of a
+//      row for the second launch: measured 1.8 x slower on the memory side alone.)
 //   y / z between workgroup tiles: halo slabs (contiguous rows) + st_pencil_fixup, as in the
 //      tile variant.
 //
@@ -49,7 +52,7 @@ constexpr int PENCIL_WY = 4; // waves of a workgroup, stacked in y
 // Diagnostic builds only (tools/build_pencil_exp.sh): -DSTFEM_PENCIL_EXP=<bits> removes parts of the
 // kernel for timing (results are wrong), -DSTFEM_PENCIL_TIMELINE records phase timestamps.
 //   1 no dst / halo stores   2 no src loads   4 no middle phase   8 no forward / backward phases
-//   16 no layer barrier      32 no x-slab traffic
+//   512 src loads always from the tile's first rows    1024 dst stores always to them
 #ifndef STFEM_PENCIL_EXP
 #define STFEM_PENCIL_EXP 0
 #endif
@@ -102,9 +105,10 @@ template <int P, int NBM, int TY> struct PencilGeom {
   static constexpr int ACTIVE = CPW * NBM * N;
   static constexpr int WY = PENCIL_WY;
   static constexpr int NT = 64 * WY;
-  static constexpr int LDS_PER_WAVE = CPW * NBM * G::CBS; // transpose slab of one wave
-  static constexpr int MAIL = 64 * N;                     // one mailbox buffer: [z][lane]
-  static constexpr int LDS_DOUBLES = WY * LDS_PER_WAVE + (WY - 1) * 2 * MAIL;
+  static constexpr int MAIL = 64 * N; // one mailbox buffer: [z][lane]
+  // transpose slabs, mailboxes, hand-over counters + tile number (dynamic LDS: above the 64 KB static limit for Q4)
+  static constexpr size_t LDS_BYTES =
+    sizeof(real_t) * (size_t(WY) * PencilCore<P, NBM>::LDS_PER_WAVE + size_t(WY - 1) * 2 * MAIL) + sizeof(int) * (2 * WY + 4);
 };
 
 __device__ __forceinline__ int pchunk_begin(int c, int ncz, int ntc) { return int(int64_t(c) * ncz / ntc); }
@@ -125,46 +129,76 @@ __device__ __forceinline__ void lds_barrier()
 
 // per-lane roles, kept in ONE register (a bool per role would pin two SGPRs each)
 enum : unsigned {
-  LF_IN = 1,      // feeds an input block
-  LF_OUT = 2,     // produces an output block
-  LF_FIRST = 4,   // first cell of the pencil row
-  LF_LAST = 8,    // last (active) cell of the pencil row
-  LF_ADDLO = 16,  // even pencil: receives the left neighbour's face
-  LF_ADDHI = 32,  // even pencil: receives the right neighbour's face
-  LF_ST = 64,     // stores its column of the finished rows
-  LF_XCON = 128,  // its column is a Dirichlet column (x faces)
-  LF_XS = 256     // reads (even) / writes (odd) an x-slab
+  LF_IN = 1,    // feeds an input block
+  LF_OUT = 2,   // produces an output block
+  LF_LAST = 8,  // last (active) cell of the pencil row: keeps its own x = P slot in the core
+  LF_ST = 64,   // stores its column of the finished rows
+  LF_XCON = 128 // its column is a Dirichlet column (x faces)
 };
 
-template <int P, int NBM, int TY, bool ADD, bool COEF, int COLOR>
+template <int P, int NBM, int TY, bool ADD, bool COEF>
 __global__ __launch_bounds__(64 * PENCIL_WY, 2)
 void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
 {
   using PG = PencilGeom<P, NBM, TY>;
   using Core = PencilCore<P, NBM>;
   constexpr int N = PG::N, NN = N * N, CPW = PG::CPW, WY = PG::WY;
-  constexpr bool odd = COLOR == 1;
-  __shared__ real_t smem[PG::LDS_DOUBLES];
+  // LDS: [wave][transpose slab] | [wave 0..WY-2][2 mailbox buffers] | prod[WY], cons[WY], tile number
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  real_t *smem = reinterpret_cast<real_t *>(smem_raw);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  real_t *lds = smem + wave * PG::LDS_PER_WAVE;
-  real_t *mail_base = smem + WY * PG::LDS_PER_WAVE;
+  real_t *lds = smem + wave * Core::LDS_PER_WAVE;
+  real_t *mail_base = smem + WY * Core::LDS_PER_WAVE;
   real_t *mail_out = mail_base + wave * 2 * PG::MAIL;            // written by waves 0 .. WY-2
   const real_t *mail_in = mail_base + (wave - 1) * 2 * PG::MAIL; // read by waves 1 .. WY-1
+  // hand-over counters of the mailboxes: prod[w] = layers whose top row wave w has delivered,
+  // cons[w] = layers wave w has taken from the wave below.  No workgroup barrier inside a tile.
+  volatile int *flags = reinterpret_cast<volatile int *>(mail_base + (WY - 1) * 2 * PG::MAIL);
+  volatile int *prod = flags, *cons = flags + WY;
+  volatile int *s_tile = flags + 2 * WY;
+  auto flag_wait = [&](volatile int *f, int target) {
+    while (*f < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
 
-  // workgroup tile of this launch's x colour
-  // (experiment 64: all pencils in ONE launch, x faces wrong - what would a colour-free decomposition cost?)
-  const int ntxh = (PEX & 64) ? pp.ntx : (pp.ntx - COLOR + 1) / 2;
-  const int nblocks = ntxh * pp.ntyw * pp.ntc;
-  const int id = plogical_block(blockIdx.x, nblocks);
-  const int tx = (PEX & 64) ? id % ntxh : 2 * (id % ntxh) + COLOR, tyw = (id / ntxh) % pp.ntyw, tc = id / (ntxh * pp.ntyw);
-  const int wg_tile = tx + pp.ntx * (tyw + pp.ntyw * tc);
+  // Workgroup tiles are handed out at run time (the resident workgroups of the launch pull tile
+  // numbers until none is left).  Every XCD has its own contiguous range of tiles and its own
+  // counter, so that x-neighbouring pencils run at the same time behind one L2; a workgroup whose
+  // XCD has run dry takes tiles of the others.
+  const int nblocks = pp.ntx * pp.ntyw * pp.ntc;
+  unsigned xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7;
+  for (;;) {
+  __syncthreads(); // every wave is done with the previous tile (its mailboxes, the tile number)
+  if (threadIdx.x == 0) {
+    int t = -1;
+    const int per = nblocks / 8, rem = nblocks % 8;
+    for (int q = 0; q < 8 && t < 0; ++q) {
+      const int x = (xcc + q) & 7;
+      const int lo = x * per + min(x, rem), n = per + (x < rem ? 1 : 0);
+      if (n > 0) {
+        const int k = atomicAdd(pp.work + 32 * x, 1);
+        if (k < n) t = lo + k;
+      }
+    }
+    *s_tile = t;
+  }
+  prod[wave] = 0;
+  cons[wave] = 0;
+  __syncthreads();
+  const int id = __builtin_amdgcn_readfirstlane(*s_tile); // (wave-uniform: keeps everything derived from it in SGPRs)
+  if (id < 0) break;
+  // pencil tx owns the cells [tx (CPW-1), (tx+1) (CPW-1)) of its row and computes cell tx (CPW-1) - 1 in slot 0 as well
+  const int tx = id % pp.ntx, tyw = (id / pp.ntx) % pp.ntyw, tc = id / (pp.ntx * pp.ntyw);
+  const int wg_tile = id;
   const int wy = tyw * WY + wave; // global pencil row
-  const int cx0 = tx * CPW, cy0 = wy * TY;
+  const int cx0 = tx * (CPW - 1) - 1, cy0 = wy * TY;
   const int cz0 = pchunk_begin(tc, prm.ncz, pp.ntc);
   const int nlay = pchunk_begin(tc + 1, prm.ncz, pp.ntc) - cz0;
-  const int ncx_t = min(CPW, prm.ncx - cx0);
+  const int nslot = min(CPW, prm.ncx - cx0);          // slots [0, nslot) hold cells (slot 0 of the first pencil does not)
   const int ncy_t = max(0, min(TY, prm.ncy - cy0)); // wave-uniform
   const bool last_x = tx == pp.ntx - 1, last_z = tc == pp.ntc - 1;
   const bool mesh_top = cy0 + TY >= prm.ncy; // this pencil's top row is the mesh's
@@ -172,7 +206,6 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   const bool top_mail = !mesh_top && wave < WY - 1;
   const bool top_halo = !mesh_top && wave == WY - 1;
   const bool has_lower = wave > 0; // the wave below completes this pencil's y = 0 row one layer late
-  const bool has_left = tx > 0, has_right = !last_x;
 
   const bool lane_ok = lane < PG::ACTIVE;
   const int l = lane_ok ? lane : 0;
@@ -180,20 +213,17 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   const int X = P * c + i; // column within the pencil's rows
   unsigned lf = 0;
   {
-    const bool cell_ok = lane_ok && c < ncx_t && ncy_t > 0;
-    const int cxl = cx0 + (cell_ok ? c : 0);
+    const bool cell_ok = lane_ok && c < nslot && cx0 + c >= 0 && ncy_t > 0;
+    const int cxl = cx0 + (cell_ok ? c : 1);
     const bool out = cell_ok && blk < prm.nbo;
-    const bool first = c == 0, last = c == ncx_t - 1;
-    // columns of the rows this lane stores: x-node P of a cell is the next cell's node 0; the two end
-    // columns of the pencil belong to the even pencils (or to the mesh boundary)
-    const bool st = out && ((i < P && !(X == 0 && odd && has_left)) || (i == P && last && (!odd || last_x)));
+    // columns of the rows this lane stores: x-node P of a cell is the next cell's node 0; the halo slot
+    // stores nothing; the x = P column of the row's last cell exists only at the mesh boundary
+    const bool st = out && c > 0 && (i < P || cxl == prm.ncx - 1);
     const bool xcon = ((prm.dmask & 1) && cxl == 0 && i == 0) || ((prm.dmask & 2) && cxl == prm.ncx - 1 && i == P);
-    const bool lo = first && has_left, hi = last && has_right;
-    lf = (cell_ok && blk < prm.nbi ? LF_IN : 0) | (out ? LF_OUT : 0) | (first ? LF_FIRST : 0) | (last ? LF_LAST : 0) |
-         (!odd && lo ? LF_ADDLO : 0) | (!odd && hi ? LF_ADDHI : 0) | (st ? LF_ST : 0) | (xcon ? LF_XCON : 0) |
-         (out && (lo || hi) ? LF_XS : 0);
+    lf = (cell_ok && blk < prm.nbi ? LF_IN : 0) | (out ? LF_OUT : 0) | (c == nslot - 1 ? LF_LAST : 0) |
+         (st ? LF_ST : 0) | (xcon ? LF_XCON : 0);
   }
-  const int cx = cx0 + ((lf & (LF_IN | LF_OUT)) ? c : 0);
+  const int cx = cx0 + ((lf & (LF_IN | LF_OUT)) ? c : 1);
 
   // eigenvalue of this lane's z-mode in the middle phase of the core
   real_t lzk = prm.fd_lz[0];
@@ -212,23 +242,10 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   const int64_t lane_off = int64_t(P) * cx + i + int64_t(prm.nx) * (int64_t(P) * cy0) + plane_stride * (int64_t(P) * cz0);
   const real_t *src_lane = prm.src[(lf & LF_IN) ? blk : 0] + lane_off;
   real_t *dst_lane = prm.dst[(lf & LF_OUT) ? blk : 0] + lane_off;
-  const bool xy_boundary = ((prm.dmask & 1) && tx == 0) || ((prm.dmask & 2) && last_x) ||
+  const bool xy_boundary = ((prm.dmask & 1) && tx <= 1) || ((prm.dmask & 2) && last_x) ||
                            ((prm.dmask & 4) && cy0 == 0) || ((prm.dmask & 8) && mesh_top);
   const int64_t cells_per_layer = int64_t(prm.ncx) * prm.ncy;
-
-  // x-slabs: [chunk][pencil row][tx][blk][layer][cyl][k][XS] (N values, padded to an even count).
-  // Even pencils read the odd neighbours' (first cell: left neighbour's right face, last cell: right
-  // neighbour's left face); odd pencils write their own.
-  constexpr int XS = N + (N & 1);
-  real_t *xs_ptr = nullptr;
-  {
-    const int64_t xs_tile = int64_t(NBM) * pp.lz * TY * N * XS;
-    const bool lo = lf & LF_FIRST; // (a one-cell pencil is always the last of its row: its left face)
-    real_t *base = odd ? (lo && has_left ? pp.xl : pp.xr) : (lo && has_left ? pp.xr : pp.xl);
-    const int tx_ = odd ? tx : (lo && has_left ? tx - 1 : tx + 1);
-    if (lf & LF_XS)
-      xs_ptr = base + ((int64_t(tc) * (pp.ntyw * WY) + wy) * pp.ntx + tx_) * xs_tile + (int64_t(blk) * pp.lz * TY * N + i) * XS;
-  }
+  const int64_t cell0 = cx + int64_t(prm.ncx) * cy0 + cells_per_layer * cz0; // per-cell coefficients
 
   real_t ycar[N], zcar[TY][P], pend[P], ztop = real_t(0), zfin0 = real_t(0);
   STFEM_UNROLL
@@ -240,25 +257,39 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   STFEM_UNROLL
   for (int z = 0; z < P; ++z) pend[z] = real_t(0);
 
-  // (the group's base pointers are made opaque: loop strength reduction otherwise keeps one 64-bit
-  // induction pointer per row of the gather and of the scatter alive through the whole loop, ~80 VGPRs)
   // ASYNC: the hot loads / stores are issued from asm statements (see vm_load); the accumulating
   // instantiations (dst += ...) keep compiler-tracked accesses throughout
   constexpr bool ASYNC = !ADD;
   constexpr int MAIN_STORES_MIN = P * (P - 1); // dst stores every cell group issues at least
-  auto load_group = [&](const real_t *s, real_t (&PA)[NN]) {
-    asm volatile("" : "+v"(s));
+  // One row (fixed y, all z) of a cell group's src planes; `row` walks from row to row.  The pointers
+  // are stepped (and made opaque) instead of indexed: with base + uniform offset addressing the
+  // compiler keeps a 64-bit offset per row of the gather and of the scatter in SGPRs through the
+  // whole loop, far more than there are, and reads them back from VGPR lanes at every use.
+  auto step = [&](auto *&q, int64_t n) {
+    q += n;
+    asm volatile("" : "+v"(q));
+  };
+  auto load_row = [&](const real_t *&row, int y, real_t (&PA)[NN]) {
+    const real_t *q = row;
     STFEM_UNROLL
-    for (int y = 0; y < N; ++y)
-      STFEM_UNROLL
     for (int z = 0; z < N; ++z) {
       if (PEX & 2) PA[y * N + z] = real_t(y + z);
-      else if (ASYNC) vm_load(PA[y * N + z], s + (plane_stride * z + int64_t(prm.nx) * y));
-      else PA[y * N + z] = s[plane_stride * z + int64_t(prm.nx) * y];
+      else if (ASYNC) vm_load(PA[y * N + z], q);
+      else PA[y * N + z] = *q;
+      if (z + 1 < N) step(q, plane_stride);
+    }
+    step(row, prm.nx);
+  };
+  auto load_coef = [&](int64_t cell, real_t &fK, real_t &fM) { // (operators.h:1060-1087)
+    if (ASYNC) {
+      if (prm.coef_lap) vm_load(fK, prm.coef_lap + cell);
+      if (prm.coef_mass) vm_load(fM, prm.coef_mass + cell);
+    } else {
+      if (prm.coef_lap) fK = prm.coef_lap[cell];
+      if (prm.coef_mass) fM = prm.coef_mass[cell];
     }
   };
   const unsigned long long st_mask = __builtin_amdgcn_ballot_w64((lf & LF_ST) != 0);
-  const unsigned long long xs_mask = __builtin_amdgcn_ballot_w64((lf & LF_XS) != 0);
   real_t sink = real_t(0); // experiments only
   auto put = [&](real_t *q, real_t v) {
     if (PEX & 1) sink += v;
@@ -266,22 +297,29 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
     else *q = v;
   };
 #ifdef STFEM_PENCIL_TIMELINE
-  // [block][wave][layer][cyl][8] 100 MHz timestamps of the even-colour launch
-#define PTL(k)                                                                                          \
-  do {                                                                                                  \
-    if (COLOR == 0 && pp.timeline && lane == 0)                                                         \
-      pp.timeline[(((int64_t(blockIdx.x) * WY + wave) * pp.lz + layer) * TY + cyl) * 8 + (k)] = wall_clock64(); \
+  // [tile][wave][layer][cyl][8] 100 MHz timestamps
+#define PTL(k)                                                                                               \
+  do {                                                                                                       \
+    if (pp.timeline && lane == 0)                                                                            \
+      pp.timeline[(((int64_t(wg_tile) * WY + wave) * pp.lz + layer) * TY + cyl) * 8 + (k)] = wall_clock64(); \
   } while (0)
 #else
 #define PTL(k) do {} while (0)
 #endif
 
-  real_t PA[NN];
+  // src planes and coefficients of the current cell group (the next group's are fetched during the
+  // middle phase of the current one)
+  real_t PA[NN], fK = real_t(1), fM = real_t(1);
   if (ncy_t > 0) {
-    load_group(src_lane, PA);
+    const real_t *s = src_lane;
+    asm volatile("" : "+v"(s));
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y) load_row(s, y, PA);
+    if (COEF) load_coef(cell0, fK, fM);
     if (ASYNC) {
       vm_wait<0>();
       pin(PA);
+      asm volatile("" : "+v"(fK), "+v"(fM));
     }
   }
 
@@ -293,11 +331,14 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
 
     // the row this pencil kept back in the previous layer: the wave below has delivered its part
     if (has_lower && layer > 0 && ncy_t > 0) {
+      flag_wait(prod + (wave - 1), layer);
       const real_t *m = mail_in + ((layer - 1) & 1) * PG::MAIL + lane;
       real_t *d = dst_lane + plane_stride * (int64_t(P) * (layer - 1));
       real_t v[P];
       STFEM_UNROLL
       for (int z = 0; z < P; ++z) v[z] = pend[z] + m[64 * z];
+      asm volatile("" ::: "memory");
+      cons[wave] = layer;
       if (lf & LF_ST) {
         STFEM_UNROLL
         for (int z = 0; z < P; ++z) put(d + plane_stride * z, (lf & LF_XCON) ? real_t(0) : v[z]);
@@ -311,67 +352,16 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
       // (operators.h:1123-1128: read_dof_values / distribute_local_to_global skip them); a face DoF
       // is flagged by both cells that share it, so zeroing the cell results before the carries
       // leaves every carried or handed-over partial sum of a constrained DoF zero too
-      auto zero_constrained = [&](real_t (&A)[NN]) {
-        const bool xc = lf & LF_XCON;
+      auto constrained_dof = [&](int y, int z) -> bool {
+        return (lf & LF_XCON) || (y == 0 && y_lo) || (y == P && y_hi) || (z == 0 && z_lo) || (z == P && z_hi);
+      };
+      PTL(0);
+      if (masked) {
         STFEM_UNROLL
         for (int y = 0; y < N; ++y)
           STFEM_UNROLL
         for (int z = 0; z < N; ++z)
-          if (xc || (y == 0 && y_lo) || (y == P && y_hi) || (z == 0 && z_lo) || (z == P && z_hi)) A[y * N + z] = real_t(0);
-      };
-      PTL(0);
-      if (masked) zero_constrained(PA);
-
-      // even pencils: the odd neighbours' face sums of this cell group (issued before the src
-      // prefetch below, so that waiting for them does not wait for the prefetch)
-      real_t xin[N], xout[N];
-      STFEM_UNROLL
-      for (int y = 0; y < N; ++y) xin[y] = xout[y] = real_t(0);
-      const int xs_group = (layer * TY + cyl) * N * XS;
-      if (!odd && !(PEX & 32)) {
-        if (ASYNC) {
-          STFEM_UNROLL
-          for (int y = 0; y < N; ++y) vm_load_masked(xin[y], xs_ptr + (xs_group + y), xs_mask);
-        } else if (lf & LF_XS) {
-          STFEM_UNROLL
-          for (int y = 0; y < N; ++y) xin[y] = xs_ptr[xs_group + y];
-        }
-      }
-
-      // per-cell coefficients (operators.h:1060-1087), folded into the temporal weights in the middle
-      // phase; fetched like the slab values (older than the prefetch, waited for together with them)
-      real_t fK = real_t(1), fM = real_t(1);
-      if (COEF) {
-        const int64_t cell = cx + int64_t(prm.ncx) * cy + cells_per_layer * cz;
-        if (ASYNC) {
-          if (prm.coef_lap) vm_load(fK, prm.coef_lap + cell);
-          if (prm.coef_mass) vm_load(fM, prm.coef_mass + cell);
-        } else {
-          if (prm.coef_lap) fK = prm.coef_lap[cell];
-          if (prm.coef_mass) fM = prm.coef_mass[cell];
-        }
-      }
-
-      real_t *cb_lds = lds + (c * NBM + blk) * Core::CBS;
-      if (!(PEX & 8)) Core::forward(prm, cb_lds, i, lf & LF_IN, PA);
-      else pin(PA);
-      PTL(1);
-
-      // PA is free: fetch the next cell group of the march (lands during the middle phase)
-      {
-        const bool more_y = cyl + 1 < ncy_t;
-        if (more_y || !last_layer) {
-          const real_t *s = more_y ? src_lane + plane_stride * (int64_t(P) * layer) + int64_t(prm.nx) * (int64_t(P) * (cyl + 1))
-                                   : src_lane + plane_stride * (int64_t(P) * (layer + 1));
-          load_group(s, PA);
-        }
-        // the slab values are older than the prefetch: they have landed when at most the prefetch is in flight
-        if (ASYNC && ((!odd && !(PEX & 32)) || COEF)) {
-          if (more_y || !last_layer) vm_wait<NN>();
-          else vm_wait<0>();
-          pin(xin);
-          asm volatile("" : "+v"(fK), "+v"(fM));
-        }
+          if (constrained_dof(y, z)) PA[y * N + z] = real_t(0);
       }
       real_t aK[NBM], aM[NBM];
       STFEM_UNROLL
@@ -380,94 +370,104 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
         aM[q] = COEF ? aM0[q] * fM : aM0[q];
       }
 
+      real_t *cb_lds = lds + Core::cb_offset(c, blk);
+      if (!(PEX & 8)) Core::forward(prm, cb_lds, i, lf & LF_IN, PA);
+      else pin(PA);
+      PTL(1);
+
+      // PA is free: the next cell group of the march is fetched row by row during the middle phase
+      const bool more_y = cyl + 1 < ncy_t;
+      const bool has_next = more_y || !last_layer;
+      const int64_t next_rows = more_y ? int64_t(P) * (cyl + 1) : 0, next_planes = more_y ? int64_t(P) * layer : int64_t(P) * (layer + 1);
+      const real_t *sn = (PEX & 512) ? src_lane : src_lane + plane_stride * next_planes + int64_t(prm.nx) * next_rows; // walks
+      asm volatile("" : "+v"(sn));
+      auto prefetch_row = [&](int y) {
+        if (!has_next) return;
+        load_row(sn, y, PA);
+        if (COEF && y == N - 1)
+          load_coef(cell0 + (more_y ? int64_t(prm.ncx) * (cyl + 1) + cells_per_layer * layer : cells_per_layer * (layer + 1)), fK, fM);
+      };
       PTL(2);
-      if (!(PEX & 4))
-        Core::template middle<!odd, odd>(prm, lds, c, blk, i, lf & LF_OUT, lf & LF_FIRST, lf & LF_LAST, lf & LF_ADDLO,
-                                         lf & LF_ADDHI, lzk, aK, aM, xin, xout);
-      PTL(3);
-
-      if (odd && !(PEX & 32)) {
-        if (ASYNC) {
-          STFEM_UNROLL
-          for (int y = 0; y < N; ++y) vm_store_masked(xs_ptr + (xs_group + y), xout[y], xs_mask);
-        } else if (lf & LF_XS) {
-          STFEM_UNROLL
-          for (int y = 0; y < N; ++y) xs_ptr[xs_group + y] = xout[y];
-        }
-      }
-
-      real_t R[NN];
-      if (!(PEX & 8)) Core::backward(prm, cb_lds, i, R);
+      if (!(PEX & 4)) Core::middle(prm, lds, c, blk, i, lf & LF_OUT, lf & LF_LAST, lzk, aK, aM, prefetch_row);
       else {
         STFEM_UNROLL
-        for (int e = 0; e < NN; ++e) R[e] = xin[e % N] + real_t(e);
-        pin(R);
+        for (int y = 0; y < N; ++y) prefetch_row(y);
       }
-      if (masked) zero_constrained(R);
-      PTL(4);
+      PTL(3);
 
-      // faces shared with the previous cell of the march (y) and with the previous layer (z)
-      if (cyl > 0) {
+      // finished rows leave as they come out of the last sweep: y, z in [0, P).  The y = 0 row of a
+      // pencil with a wave below is kept back for one layer.
+      const bool defer = has_lower && cyl == 0;
+      real_t *d = (PEX & 1024) ? dst_lane // (1024: every group overwrites the same rows: the lines stay in L2)
+                               : dst_lane + plane_stride * (int64_t(P) * layer) + int64_t(prm.nx) * (int64_t(P) * cyl);
+      asm volatile("" : "+v"(d));
+      real_t *drow = d; // walks from row to row
+      real_t znew[P];
+      auto row_done = [&](int y, real_t (&r)[N]) {
+        if (masked) {
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z)
+            if (constrained_dof(y, z)) r[z] = real_t(0);
+        }
+        // faces shared with the previous cell of the march (y) and with the previous layer (z)
+        if (y == 0 && cyl > 0) {
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) r[z] += ycar[z];
+        }
+        if (y == P) {
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) ycar[z] = r[z];
+          return;
+        }
+        if (layer > 0) r[0] += zcar[0][y];
+        znew[y] = r[P];
+        if (y == 0 && defer) {
+          STFEM_UNROLL
+          for (int z = 0; z < P; ++z) pend[z] = r[z];
+          zfin0 = r[P];
+          step(drow, prm.nx);
+          return;
+        }
+        real_t *q = drow;
         STFEM_UNROLL
-        for (int z = 0; z < N; ++z) R[0 * N + z] += ycar[z];
-      }
-      if (layer > 0) {
+        for (int z = 0; z < P; ++z) {
+          if (ASYNC && !(PEX & 1)) vm_store_masked(q, r[z], st_mask);
+          else if (lf & LF_ST) put(q, r[z]);
+          step(q, plane_stride);
+        }
+        // top plane of the chunk: to dst on the last chunk, to the z-halo slab otherwise
+        if (last_layer && (lf & LF_ST)) {
+          if (last_z) put(q, r[P]);
+          else if (!(PEX & 1))
+            (pp.zh + ((int64_t(wg_tile) * NBM + blk) * pp.tYW + P * (TY * wave + cyl) + y) * pp.tX + X)[0] = r[P];
+        }
+        step(drow, prm.nx);
+      };
+      if (!(PEX & 8)) Core::backward(prm, cb_lds, i, row_done);
+      else {
         STFEM_UNROLL
-        for (int y = 0; y < P; ++y) R[y * N + 0] += zcar[0][y];
+        for (int y = 0; y < N; ++y) {
+          real_t r[N];
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) r[z] = lzk + real_t(y + z);
+          pin(r);
+          row_done(y, r);
+        }
       }
-      STFEM_UNROLL
-      for (int z = 0; z < N; ++z) ycar[z] = R[P * N + z];
+      PTL(4);
       STFEM_UNROLL
       for (int t = 0; t + 1 < TY; ++t)
         STFEM_UNROLL
       for (int y = 0; y < P; ++y) zcar[t][y] = zcar[t + 1][y];
       STFEM_UNROLL
-      for (int y = 0; y < P; ++y) zcar[TY - 1][y] = R[y * N + P];
+      for (int y = 0; y < P; ++y) zcar[TY - 1][y] = znew[y];
 
-      // finished rows: y, z in [0, P).  The y = 0 row of a pencil with a wave below is kept back.
-      const bool defer = has_lower && cyl == 0;
-      real_t *d = dst_lane + plane_stride * (int64_t(P) * layer) + int64_t(prm.nx) * (int64_t(P) * cyl);
-      asm volatile("" : "+v"(d));
-      if (defer) {
-        STFEM_UNROLL
-        for (int z = 0; z < P; ++z) pend[z] = R[0 * N + z];
-        zfin0 = R[0 * N + P];
-      }
-      if (ASYNC && !(PEX & 1)) {
-        STFEM_UNROLL
-        for (int z = 0; z < P; ++z)
-          STFEM_UNROLL
-        for (int y = 0; y < P; ++y) {
-          if (y == 0 && defer) continue;
-          vm_store_masked(d + (plane_stride * z + int64_t(prm.nx) * y), R[y * N + z], st_mask);
-        }
-      }
-      if (lf & LF_ST) {
-        if (!ASYNC || (PEX & 1)) {
-          STFEM_UNROLL
-          for (int z = 0; z < P; ++z)
-            STFEM_UNROLL
-          for (int y = 0; y < P; ++y) {
-            if (y == 0 && defer) continue;
-            put(d + plane_stride * z + int64_t(prm.nx) * y, R[y * N + z]);
-          }
-        }
-        // top plane of the chunk: to dst on the last chunk, to the z-halo slab otherwise
-        if (last_layer) {
-          real_t *zh = pp.zh + ((int64_t(wg_tile) * NBM + blk) * pp.tYW + P * (TY * wave + cyl)) * pp.tX + X;
-          STFEM_UNROLL
-          for (int y = 0; y < P; ++y) {
-            if (y == 0 && defer) continue;
-            if (last_z) put(d + plane_stride * P + int64_t(prm.nx) * y, R[y * N + P]);
-            else if (!(PEX & 1)) zh[y * pp.tX] = R[y * N + P];
-          }
-        }
-      }
       // the prefetched src planes are older than this group's dst stores
       if (ASYNC && !(PEX & 2)) {
         if (PEX & 1) vm_wait<0>();
         else vm_wait<MAIN_STORES_MIN>();
         pin(PA);
+        asm volatile("" : "+v"(fK), "+v"(fM));
       }
       PTL(5);
       // top row of the pencil
@@ -478,9 +478,12 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
         if (layer > 0) yrow[0] += ztop;
         ztop = yrow[P];
         if (top_mail) {
+          if (layer >= 2) flag_wait(cons + (wave + 1), layer - 1); // the buffer's previous content has been taken
           real_t *m = mail_out + (layer & 1) * PG::MAIL + lane;
           STFEM_UNROLL
           for (int z = 0; z < N; ++z) m[64 * z] = yrow[z];
+          asm volatile("" ::: "memory");
+          prod[wave] = layer + 1;
         } else if (lf & LF_ST) {
           if (top_halo) {
             real_t *yh = pp.yh + ((int64_t(wg_tile) * NBM + blk) * pp.zp + P * layer) * pp.tX + X;
@@ -498,12 +501,6 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
         }
       }
     }
-#ifdef STFEM_PENCIL_TIMELINE
-    {
-      const int cyl = 0;
-      PTL(6);
-    }
-#endif
     // pencils with fewer than TY cell rows keep the z-carry slots aligned
     for (int r = ncy_t; r < TY && ncy_t > 0; ++r) {
       real_t t0[P];
@@ -516,18 +513,12 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
       STFEM_UNROLL
       for (int y = 0; y < P; ++y) zcar[TY - 1][y] = t0[y];
     }
-    if (!(PEX & 16)) lds_barrier(); // the mailboxes of this layer are complete
-#ifdef STFEM_PENCIL_TIMELINE
-    {
-      const int cyl = 0;
-      PTL(7);
-    }
-#endif
   }
   if (PEX && sink == real_t(1.2345e30)) pp.zh[0] = sink; // experiment sink, never true
 
   // last layer's kept-back row, and the y = 0 row of the chunk's top plane
   if (has_lower && ncy_t > 0) {
+    flag_wait(prod + (wave - 1), nlay);
     const real_t *m = mail_in + ((nlay - 1) & 1) * PG::MAIL + lane;
     real_t *d = dst_lane + plane_stride * (int64_t(P) * (nlay - 1));
     real_t v[N];
@@ -542,6 +533,7 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
       else (pp.zh + ((int64_t(wg_tile) * NBM + blk) * pp.tYW + P * TY * wave) * pp.tX + X)[0] = xc ? real_t(0) : v[P];
     }
   }
+  } // next tile
 }
 
 // Adds the halo partial sums of the workgroup tiles below in y / z to the rows a tile owns on its
@@ -554,13 +546,13 @@ __global__ __launch_bounds__(256) void st_pencil_fixup(const SweepParams prm, co
   const int has_y = tyw > 0, has_z = tc > 0;
   if (!(has_y | has_z)) return;
   const int cyw = ty * PENCIL_WY; // cell rows of a workgroup tile
-  const int cx0 = tx * cpw, cy0 = tyw * cyw, cz0 = pchunk_begin(tc, prm.ncz, pp.ntc);
-  const int ncx_t = min(cpw, prm.ncx - cx0), ncy_t = min(cyw, prm.ncy - cy0);
+  const int cx0 = tx * (cpw - 1) - 1, cy0 = tyw * cyw, cz0 = pchunk_begin(tc, prm.ncz, pp.ntc);
+  const int nslot = min(cpw, prm.ncx - cx0), ncy_t = min(cyw, prm.ncy - cy0);
   const int nlay = pchunk_begin(tc + 1, prm.ncz, pp.ntc) - cz0;
   const bool last_x = tx == pp.ntx - 1, last_y = tyw == pp.ntyw - 1, last_z = tc == pp.ntc - 1;
-  const bool odd = tx & 1;
-  // stored columns of the tile's rows (see st_lane in the sweep)
-  const int x_begin = (odd && tx > 0) ? 1 : 0, x_end = P * ncx_t + ((!odd || last_x) ? 1 : 0);
+  // stored columns of the tile's rows (see LF_ST in the sweep): everything but the halo slot, and the
+  // mesh's last column
+  const int x_begin = P, x_end = P * nslot + (last_x ? 1 : 0);
   const int Yn = P * ncy_t + (last_y ? 1 : 0), Zn = P * nlay + (last_z ? 1 : 0);
   const int lpr = pp.tX <= 32 ? 32 : 64, nrg = 256 / lpr;
   const int X = threadIdx.x % lpr, rg = threadIdx.x / lpr;
@@ -615,33 +607,33 @@ __global__ __launch_bounds__(256) void st_pencil_fixup(const SweepParams prm, co
     }
 }
 
-template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, const PencilPlan &pp0, hipStream_t st)
+template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, const PencilPlan &pp, hipStream_t st)
 {
   using PG = PencilGeom<P, NBM, TY>;
-  PencilPlan pp = pp0;
   (void)hipGetLastError();
   const bool coef = prm.coef_lap || prm.coef_mass;
-  for (int colour = 1; colour >= 0; --colour) { // odd pencils first: they feed the even ones
-    const int ntxh = (PEX & 64) ? (colour == 0 ? pp.ntx : 0) : (pp.ntx - colour + 1) / 2;
-    const int nblocks = ntxh * pp.ntyw * pp.ntc;
-    if (nblocks == 0) continue;
-#define STFEM_LAUNCH(AA, CC)                                                                                   \
-  do {                                                                                                        \
-    if (colour == 1)                                                                                          \
-      hipLaunchKernelGGL((st_sweep_pencil<P, NBM, TY, AA, CC, 1>), dim3(nblocks), dim3(PG::NT), 0, st, prm, pp); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((st_sweep_pencil<P, NBM, TY, AA, CC, 0>), dim3(nblocks), dim3(PG::NT), 0, st, prm, pp); \
+  const int nblocks = pp.ntx * pp.ntyw * pp.ntc;
+  if (hipMemsetAsync(pp.work, 0, 8 * 32 * sizeof(int), st) != hipSuccess) return -3;
+  const int grid = nblocks < pp.grid ? nblocks : pp.grid;
+#define STFEM_LAUNCH(AA, CC)                                                                                       \
+  do {                                                                                                            \
+    static bool lds_set = false;                                                                                  \
+    if (!lds_set) {                                                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&st_sweep_pencil<P, NBM, TY, AA, CC>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(PG::LDS_BYTES)) != hipSuccess)      \
+        return -3;                                                                                                \
+      lds_set = true;                                                                                             \
+    }                                                                                                             \
+    hipLaunchKernelGGL((st_sweep_pencil<P, NBM, TY, AA, CC>), dim3(grid), dim3(PG::NT), PG::LDS_BYTES, st, prm, pp); \
   } while (0)
-    if (pp.add && coef) STFEM_LAUNCH(true, true);
-    else if (pp.add) STFEM_LAUNCH(true, false);
-    else if (coef) STFEM_LAUNCH(false, true);
-    else STFEM_LAUNCH(false, false);
+  if (pp.add && coef) STFEM_LAUNCH(true, true);
+  else if (pp.add) STFEM_LAUNCH(true, false);
+  else if (coef) STFEM_LAUNCH(false, true);
+  else STFEM_LAUNCH(false, false);
 #undef STFEM_LAUNCH
-    if (hipGetLastError() != hipSuccess) return -3;
-  }
+  if (hipGetLastError() != hipSuccess) return -3;
   if (pp.ntyw > 1 || pp.ntc > 1) {
-    hipLaunchKernelGGL((st_pencil_fixup<P>), dim3(pp.ntx * pp.ntyw * pp.ntc, prm.nbo, 2), dim3(256), 0, st, prm, pp, NBM,
-                       PG::CPW, TY);
+    hipLaunchKernelGGL((st_pencil_fixup<P>), dim3(nblocks, prm.nbo, 2), dim3(256), 0, st, prm, pp, NBM, PG::CPW, TY);
     if (hipGetLastError() != hipSuccess) return -3;
   }
   return 0;
