@@ -61,6 +61,7 @@ struct PencilPlan {
   int cpw, ty;        // cell slots per wave in x (cpw - 1 owned + the halo slot), cell rows per wave in y
   int ntx, ntyw, ntc; // pencils in x, workgroup tiles in y, chunks in z
   int lz;             // cell layers per chunk (longest)
+  int zb[65];         // first layer of every chunk, zb[ntc] = ncz (long chunks first, short ones last)
   int tX, tYW, zp;    // slab extents: P*cpw+1, P*ty*4+1, P*lz+1
   real_t *yh, *zh;    // halo slabs: yh[tile][block][zl][X], zh[tile][block][Y][X]
   int add;            // accumulate into dst instead of overwriting

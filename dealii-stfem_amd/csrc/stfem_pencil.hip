@@ -111,21 +111,7 @@ template <int P, int NBM, int TY> struct PencilGeom {
     sizeof(real_t) * (size_t(WY) * PencilCore<P, NBM>::LDS_PER_WAVE + size_t(WY - 1) * 2 * MAIL) + sizeof(int) * (2 * WY + 4);
 };
 
-__device__ __forceinline__ int pchunk_begin(int c, int ncz, int ntc) { return int(int64_t(c) * ncz / ntc); }
 
-// blocks b, b+8, ... share an XCD: give every XCD one contiguous range of workgroup tiles
-__device__ __forceinline__ int plogical_block(int b, int nblocks)
-{
-  const int per = nblocks / 8, rem = nblocks % 8;
-  const int xcd = b % 8, slot = b / 8;
-  return xcd * per + min(xcd, rem) + slot;
-}
-
-// only LDS traffic has to be complete at the layer barrier: global loads and stores stay in flight
-__device__ __forceinline__ void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // per-lane roles, kept in ONE register (a bool per role would pin two SGPRs each)
 enum : unsigned {
@@ -163,11 +149,12 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
     asm volatile("" ::: "memory");
   };
 
-  // Workgroup tiles are handed out at run time (the resident workgroups of the launch pull tile
-  // numbers until none is left).  Every XCD has its own contiguous range of tiles and its own
-  // counter, so that x-neighbouring pencils run at the same time behind one L2; a workgroup whose
-  // XCD has run dry takes tiles of the others.
-  const int nblocks = pp.ntx * pp.ntyw * pp.ntc;
+  // Workgroup tiles are handed out at run time: the resident workgroups of the launch pull tile
+  // numbers until none is left.  Tiles are numbered chunk by chunk (the long z-chunks first, the
+  // short ones last, so that the launch ends evenly), x fastest within a chunk.  Every XCD serves one
+  // contiguous piece of every chunk with its own counter, so that x-neighbouring pencils run at the
+  // same time behind one L2; a workgroup whose XCD has run dry takes tiles of the others.
+  const int ncol = pp.ntx * pp.ntyw; // tiles of one z-chunk
   unsigned xcc = 0;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7;
@@ -175,13 +162,13 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   __syncthreads(); // every wave is done with the previous tile (its mailboxes, the tile number)
   if (threadIdx.x == 0) {
     int t = -1;
-    const int per = nblocks / 8, rem = nblocks % 8;
+    const int per = ncol / 8, rem = ncol % 8;
     for (int q = 0; q < 8 && t < 0; ++q) {
       const int x = (xcc + q) & 7;
-      const int lo = x * per + min(x, rem), n = per + (x < rem ? 1 : 0);
+      const int lo = x * per + min(x, rem), n = per + (x < rem ? 1 : 0); // this XCD's piece of a chunk
       if (n > 0) {
         const int k = atomicAdd(pp.work + 32 * x, 1);
-        if (k < n) t = lo + k;
+        if (k < n * pp.ntc) t = (k / n) * ncol + lo + k % n;
       }
     }
     *s_tile = t;
@@ -196,8 +183,8 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   const int wg_tile = id;
   const int wy = tyw * WY + wave; // global pencil row
   const int cx0 = tx * (CPW - 1) - 1, cy0 = wy * TY;
-  const int cz0 = pchunk_begin(tc, prm.ncz, pp.ntc);
-  const int nlay = pchunk_begin(tc + 1, prm.ncz, pp.ntc) - cz0;
+  const int cz0 = pp.zb[tc];
+  const int nlay = pp.zb[tc + 1] - cz0;
   const int nslot = min(CPW, prm.ncx - cx0);          // slots [0, nslot) hold cells (slot 0 of the first pencil does not)
   const int ncy_t = max(0, min(TY, prm.ncy - cy0)); // wave-uniform
   const bool last_x = tx == pp.ntx - 1, last_z = tc == pp.ntc - 1;
@@ -259,7 +246,7 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
 
   // ASYNC: the hot loads / stores are issued from asm statements (see vm_load); the accumulating
   // instantiations (dst += ...) keep compiler-tracked accesses throughout
-  constexpr bool ASYNC = !ADD;
+  constexpr bool ASYNC = !ADD && sizeof(real_t) == 8; // (fp32: tools/check_async.py finds register reuse under in-flight loads)
   constexpr int MAIN_STORES_MIN = P * (P - 1); // dst stores every cell group issues at least
   // One row (fixed y, all z) of a cell group's src planes; `row` walks from row to row.  The pointers
   // are stepped (and made opaque) instead of indexed: with base + uniform offset addressing the
@@ -542,13 +529,15 @@ template <int P>
 __global__ __launch_bounds__(256) void st_pencil_fixup(const SweepParams prm, const PencilPlan pp, int nbm, int cpw, int ty)
 {
   const int id = blockIdx.x;
+  // the sweep that fed this launch is complete: zero its tile counters for the next sweep
+  if (id == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) pp.work[32 * threadIdx.x] = 0;
   const int tx = id % pp.ntx, tyw = (id / pp.ntx) % pp.ntyw, tc = id / (pp.ntx * pp.ntyw);
   const int has_y = tyw > 0, has_z = tc > 0;
   if (!(has_y | has_z)) return;
   const int cyw = ty * PENCIL_WY; // cell rows of a workgroup tile
-  const int cx0 = tx * (cpw - 1) - 1, cy0 = tyw * cyw, cz0 = pchunk_begin(tc, prm.ncz, pp.ntc);
+  const int cx0 = tx * (cpw - 1) - 1, cy0 = tyw * cyw, cz0 = pp.zb[tc];
   const int nslot = min(cpw, prm.ncx - cx0), ncy_t = min(cyw, prm.ncy - cy0);
-  const int nlay = pchunk_begin(tc + 1, prm.ncz, pp.ntc) - cz0;
+  const int nlay = pp.zb[tc + 1] - cz0;
   const bool last_x = tx == pp.ntx - 1, last_y = tyw == pp.ntyw - 1, last_z = tc == pp.ntc - 1;
   // stored columns of the tile's rows (see LF_ST in the sweep): everything but the halo slot, and the
   // mesh's last column
@@ -560,7 +549,7 @@ __global__ __launch_bounds__(256) void st_pencil_fixup(const SweepParams prm, co
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
   const int64_t g0 = int64_t(P) * cx0 + X + int64_t(prm.nx) * (int64_t(P) * cy0) + plane_stride * (int64_t(P) * cz0);
   const int tid_y = id - pp.ntx, tid_z = id - pp.ntx * pp.ntyw, tid_yz = tid_z - pp.ntx;
-  const int top_below = has_z ? P * (cz0 - pchunk_begin(tc - 1, prm.ncz, pp.ntc)) : 0;
+  const int top_below = has_z ? P * (cz0 - pp.zb[tc - 1]) : 0;
   const int j = blockIdx.y;
   real_t *d = prm.dst[j] + g0;
   const int64_t sy = int64_t(pp.zp) * pp.tX, sz = int64_t(pp.tYW) * pp.tX;
@@ -613,7 +602,6 @@ template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, c
   (void)hipGetLastError();
   const bool coef = prm.coef_lap || prm.coef_mass;
   const int nblocks = pp.ntx * pp.ntyw * pp.ntc;
-  if (hipMemsetAsync(pp.work, 0, 8 * 32 * sizeof(int), st) != hipSuccess) return -3;
   const int grid = nblocks < pp.grid ? nblocks : pp.grid;
 #define STFEM_LAUNCH(AA, CC)                                                                                       \
   do {                                                                                                            \
@@ -632,21 +620,26 @@ template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, c
   else STFEM_LAUNCH(false, false);
 #undef STFEM_LAUNCH
   if (hipGetLastError() != hipSuccess) return -3;
+  // (the tile counters are zero on entry: zeroed at allocation and again after every sweep)
   if (pp.ntyw > 1 || pp.ntc > 1) {
     hipLaunchKernelGGL((st_pencil_fixup<P>), dim3(nblocks, prm.nbo, 2), dim3(256), 0, st, prm, pp, NBM, PG::CPW, TY);
     if (hipGetLastError() != hipSuccess) return -3;
-  }
+  } else if (hipMemsetAsync(pp.work, 0, 8 * 32 * sizeof(int), st) != hipSuccess)
+    return -3;
   return 0;
 }
 
+// cell rows per pencil: two, except where the second set of z-carry registers makes the kernel spill
+// (Q4 with three temporal blocks; tools/check_async.py fails the build if an instantiation spills)
+constexpr int pencil_ty(int p, int nbm) { return (p == 4 && nbm >= 3) ? 1 : 2; }
+
 template <int P, int NBM> int launch_pencil_t(const SweepParams &prm, const PencilPlan &pp, hipStream_t st)
 {
-  if (Geometry<P, NBM>::CELLS_PER_WAVE < 2) return -2; // one cell per wave: both end faces in one lane (tile variant)
-  switch (pp.ty) {
-    case 1: return launch_pencil_ty<P, NBM, 1>(prm, pp, st);
-    case 2: return launch_pencil_ty<P, NBM, 2>(prm, pp, st);
-    default: return -2;
-  }
+  if (Geometry<P, NBM>::CELLS_PER_WAVE < 2) return -2; // needs the halo slot and at least one owned cell
+  if (pp.ty == 1) return launch_pencil_ty<P, NBM, 1>(prm, pp, st);
+  if constexpr (pencil_ty(P, NBM) == 2)
+    if (pp.ty == 2) return launch_pencil_ty<P, NBM, 2>(prm, pp, st);
+  return -2;
 }
 
 } // namespace
@@ -690,6 +683,7 @@ int pencil_geometry(int p, int nbm, int ty, PencilPlan &plan)
 {
   if (p < 1 || p > 4) return -2;
   nbm = round_nbm(nbm);
+  if (ty < 1 || ty > pencil_ty(p, nbm)) ty = pencil_ty(p, nbm);
   // more than three temporal blocks per launch: the middle phase of the core (one x-line of every
   // input block in flight per lane) no longer fits 256 VGPRs without spilling; the tile variant
   // handles those systems
