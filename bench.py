@@ -7,9 +7,11 @@
 A "step" = one SystemMatrix::vmult (reference include/operators.h:536-559) of the all-at-once
 space-time system  dst = (Alpha (x) K + Beta (x) M) src  on synthetic data resident in HBM.
 N = 1: BASELINE.json configs[1] (72^3 cells, Q4, cG(2) -> 2 blocks, 48 275 138 space-time DoFs).
-N > 1: weak scaling - every rank owns a 72 x 72 x 72-cell z-slab of a 72 x 72 x 72N mesh (N = 8
-has exactly the cell and DoF count of configs[2]); one packed interface-plane exchange per vmult
-over RCCL send/recv, no other collective on the data path.
+N > 1: the configs[2] mesh type (vertices perturbed by 0.15 h -> general-geometry path), z-slabs,
+one packed interface-plane exchange per vmult over RCCL send/recv, no other collective on the data
+path.  Default "weak": every rank owns a 72 x 72 x 72-cell slab of a 72 x 72 x 72N mesh (N = 8 has
+exactly the cell and DoF count of configs[2]); --scaling strong: the fixed 144^3 configs[2] mesh
+cut into N slabs (run it at N = 1 too for a strong-scaling curve).  The JSON says which ran.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
 """
@@ -79,8 +81,13 @@ def main():
     ap.add_argument("--cells", type=int, default=72, help="cells per direction per GPU")
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--time-degree", type=int, default=2)
-    ap.add_argument("--distort", type=float, default=0.0,
-                    help="interior-vertex jitter in units of h (0.15 = BASELINE configs[2] mesh); 0 = Cartesian")
+    ap.add_argument("--distort", type=float, default=None,
+                    help="interior-vertex jitter in units of h (0.15 = BASELINE configs[2] mesh); 0 = Cartesian. "
+                         "Default: 0 at --gpus 1 (configs[1]), 0.15 at --gpus N > 1 (the configs[2] mesh)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = 72^3 cells per GPU (N = 8 is exactly configs[2]); strong = the fixed "
+                         "--strong-cells^3 mesh (144 = configs[2]) cut into N z-slabs")
+    ap.add_argument("--strong-cells", type=int, default=144)
     ap.add_argument("--number", choices=["double", "float"], default="double",
                     help="operator Number type: double (headline) or float (the reference's multigrid-level precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,15 +115,22 @@ def main():
     from importlib import import_module
     dmod = import_module("dealii-stfem_amd.distributed")
 
+    if args.distort is None:
+        args.distort = 0.0 if world == 1 else 0.15
     p, r, n = args.degree, args.time_degree, args.cells
-    global_nc = (n, n, n * world)
+    if args.scaling == "strong":
+        n = args.strong_cells
+        global_nc = (n, n, n)
+    else:
+        global_nc = (n, n, n * world)
+    zext = global_nc[2] / float(n)  # the domain is [0,1]^2 x [0, zext]: cubic cells
     slab = dmod.make_slab(global_nc, rank, world)
     # tests/tp_01.cc:106-109 with 9 subdivisions, refinement 3: tau = 1/144
     tau = 1.0 / 144
     Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, r, tau, 1)
     nb = Alpha.shape[0]
     if args.distort:
-        verts = stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, float(world)), args.distort, 5489,
+        verts = stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, zext), args.distort, 5489,
                                     z_range=(slab.z0, slab.z1))
         ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=verts, number=args.number,
                                        dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
@@ -213,12 +227,13 @@ def main():
             "value": total_dofs * args.steps / elapsed,
             "unit": "space-time DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64" if args.number == "double" else "f32", "data": "synthetic",
-            "config": {"workload": f"3D heat, Q{p} x cG({r}), {n}x{n}x{n * world} cells "
+            "config": {"workload": f"3D heat, Q{p} x cG({r}), {global_nc[0]}x{global_nc[1]}x{global_nc[2]} cells "
                                    + (f"perturbed ({args.distort} h vertex jitter)" if args.distort else "Cartesian")
                                    + f" slab mesh, {total_dofs} space-time DoFs"
-                                   + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else ""),
+                                   + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else "")
+                                   + (" = the BASELINE configs[2] mesh" if (global_nc, p, r, args.distort) == ((144, 144, 144), 4, 2, 0.15) else ""),
                        "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
                        "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,104 @@
+"""The N > 1 data path on ONE GPU: a mesh cut into z-slabs, every slab with its own context on
+cuda:0 (open interface faces: Slab.dirichlet_mask), the HIP sweep on every slab, the interface
+planes packed with stfem_plane_pack, copied device-to-device (what RCCL send/recv does between
+GPUs) and added with stfem_plane_unpack(add = 1).  The result must equal the single-domain HIP
+result and the CPU oracle: compress(add) + update_ghost_values around the reference's cell loop
+(include/operators.h:1016-1017) in one packed exchange per space-time vmult.
+Cartesian and perturbed meshes, fp64 and fp32, 2 and 3 slabs."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def stfem():
+    mod = importlib.import_module("dealii-stfem_amd")
+    mod.lib()
+    return mod
+
+
+@pytest.mark.parametrize("p,gnc,world,distort,number", [
+    (4, (7, 5, 6), 2, 0.0, "double"),
+    (4, (7, 5, 6), 3, 0.0, "double"),
+    (4, (4, 5, 6), 2, 0.15, "double"),
+    (2, (6, 4, 7), 3, 0.15, "double"),
+    (3, (5, 5, 4), 2, 0.0, "float"),
+    (4, (4, 3, 4), 2, 0.15, "float"),
+])
+def test_slab_exchange_on_one_gpu(stfem, oracle_mod, p, gnc, world, distort, number):
+    import torch
+    dmod = importlib.import_module("dealii-stfem_amd.distributed")
+    L = stfem.lib()
+    dev = torch.device("cuda", 0)
+    tdt = torch.float64 if number == "double" else torch.float32
+    tol = 1e-12 if number == "double" else 2e-5
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.01, 1)
+    nb = Alpha.shape[0]
+    nx, ny = p * gnc[0] + 1, p * gnc[1] + 1
+    plane = nx * ny
+    upper = (1.0, 1.0, 1.5)
+    gv = stfem.mesh_vertices(gnc, (0, 0, 0), upper, distort, 5489)
+    rng = np.random.default_rng(11)
+    ndofs = plane * (p * gnc[2] + 1)
+    X = rng.uniform(-1, 1, (nb, ndofs))
+
+    # single domain: HIP and oracle
+    gctx = stfem.MatrixFreeOperator(p, gnc, vertices=gv, number=number)
+    gA = stfem.SystemMatrix(gctx, Alpha, Beta)
+    gdst = gA.initialize_dof_vector()
+    gA.vmult(gdst, stfem.BlockVector(gctx, nb).upload(X))
+    Ygpu = gdst.download()
+    Yref = oracle_mod.Oracle(p, gnc, gv, 63).st_vmult(Alpha, Beta, X)
+    assert rel(Ygpu, Yref) < tol
+
+    # the slabs: local sweep, pack
+    ranks = []
+    for r in range(world):
+        slab = dmod.make_slab(gnc, r, world)
+        lv = stfem.mesh_vertices(gnc, (0, 0, 0), upper, distort, 5489, z_range=(slab.z0, slab.z1))
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=lv, number=number,
+                                       dirichlet_mask=slab.dirichlet_mask(63))
+        A = stfem.SystemMatrix(ctx, Alpha, Beta)
+        lo, hi = p * slab.z0 * plane, (p * slab.z1 + 1) * plane
+        src = stfem.BlockVector(ctx, nb).upload(X[:, lo:hi])  # owned + ghost plane, consistent
+        dst = A.initialize_dof_vector()
+        A.vmult(dst, src)
+        bufs = {k: torch.zeros(nb * plane, dtype=tdt, device=dev) for k in ("ts", "bs", "tr", "br")}
+        nzl = p * (slab.z1 - slab.z0) + 1
+        ranks.append(dict(slab=slab, ctx=ctx, A=A, src=src, dst=dst, bufs=bufs, nzl=nzl, lo=lo, hi=hi))
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["ts"].data_ptr(), None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["bs"].data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    # the exchange (between GPUs: ncclSend / ncclRecv of exactly these buffers)
+    for r, R in enumerate(ranks):
+        if R["slab"].has_upper:
+            ranks[r + 1]["bufs"]["br"].copy_(R["bufs"]["ts"])
+        if R["slab"].has_lower:
+            ranks[r - 1]["bufs"]["tr"].copy_(R["bufs"]["bs"])
+    torch.cuda.synchronize()
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["tr"].data_ptr(), 1, None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["br"].data_ptr(), 1, None) == 0
+    torch.cuda.synchronize()
+    for R in ranks:
+        Y = R["dst"].download()
+        assert rel(Y, Ygpu[:, R["lo"]:R["hi"]]) < tol  # owner and ghost copies of every interface plane agree
+        assert rel(Y, Yref[:, R["lo"]:R["hi"]]) < tol
+
+    # argument checks of the pack / unpack entry points (include/stfem.h)
+    R = ranks[0]
+    assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"], R["bufs"]["ts"].data_ptr(), None) != 0
+    assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, -1, R["bufs"]["ts"].data_ptr(), 1, None) != 0
+    assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, None, None) != 0
