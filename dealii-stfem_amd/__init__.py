@@ -75,6 +75,8 @@ SIGNATURES = {
     "stfem_diagonal": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
     "stfem_tensorproduct_add": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp]),
     "stfem_dot": (C.c_int, [_vp, _vp, _vp, C.c_int64, _dp, _vp]),
+    "stfem_diagonal_inverse": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
+    "stfem_st_diagonal": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _vp, _vp]),
     "stfem_plane_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "stfem_plane_unpack": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "stfem_fe_time_weights": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
@@ -289,6 +291,17 @@ class MatrixFreeOperator:
                                     d._h, stream), "stfem_diagonal")
         return d
 
+    def get_matrix_diagonal(self, stream=None):
+        """operators.h:1035-1039"""
+        return self.compute_diagonal(stream=stream)
+
+    def get_matrix_diagonal_inverse(self, stream=None):
+        """operators.h:1041-1045, 1106-1109: 1/d where |d| > sqrt(eps), 1 elsewhere."""
+        d = BlockVector(self, 1)
+        _check(lib().stfem_diagonal_inverse(self._h, self.mass_matrix_scaling, self.laplace_matrix_scaling,
+                                            d._h, stream), "stfem_diagonal_inverse")
+        return d
+
     @property
     def last_kernel_name(self):
         return lib().stfem_last_kernel_name(self._h).decode()
@@ -329,6 +342,22 @@ class SystemMatrix:
         assert self.Alpha.shape[1] == 1
         self._apply(dst, src, False, True, stream)
 
+    def _diagonal(self, inverse, stream):
+        n = self.Alpha.shape[0]
+        assert self.Alpha.shape == (n, n)
+        d = BlockVector(self.ctx, n)
+        _check(lib().stfem_st_diagonal(self.ctx._h, n, _p(self.Alpha), _p(self.Beta), int(inverse), d._h, stream),
+               "stfem_st_diagonal")
+        return d
+
+    def get_matrix_diagonal(self, stream=None):
+        """operators.h:613-623: block i = Alpha(i,i) diag K + Beta(i,i) diag M."""
+        return self._diagonal(False, stream)
+
+    def get_matrix_diagonal_inverse(self, stream=None):
+        """operators.h:625-637, as the reference combines it: 1/Alpha(i,i) (diag K)^-1 + 1/Beta(i,i) (diag M)^-1."""
+        return self._diagonal(True, stream)
+
 
 def tensorproduct_add(ctx, c, A, b, stream=None):
     """operators.h:238-250: c_i += A(i,j) b_j, skipping exact zeros."""
@@ -353,13 +382,16 @@ def stokes_block_index(n_timedofs, timestep, variable, timedof, variable_major=T
 
 
 def get_fe_time_weights_stokes(type_, r, time_step_size, n_timesteps_at_once=1):
-    """Alpha, Beta of get_fe_time_weights_stokes (fe_time.h:1242-1285): the scalar matrices of
-    get_fe_time_weights scattered into the (variable, time dof) block structure; the
-    pressure-pressure block of Alpha stays empty, Beta only couples velocity with velocity."""
-    A, B, _, _ = get_fe_time_weights(type_, r, time_step_size, n_timesteps_at_once)
+    """Alpha, Beta, Gamma, Zeta of get_fe_time_weights_stokes (fe_time.h:1242-1285): the scalar matrices
+    of get_fe_time_weights scattered into the (variable, time dof) block structure.  The
+    pressure-pressure block of Alpha stays empty, Beta only couples velocity with velocity; the
+    right-hand-side matrices Gamma, Zeta act on the velocity rows, and for cG Gamma on the pressure
+    rows as well (fe_time.h:1275-1282)."""
+    A, B, G, Z = get_fe_time_weights(type_, r, time_step_size, n_timesteps_at_once)
     n = A.shape[0]
     nt = n // n_timesteps_at_once
     Alpha = np.zeros((2 * n, 2 * n)); Beta = np.zeros((2 * n, 2 * n))
+    Gamma = np.zeros((2 * n, G.shape[1])); Zeta = np.zeros((2 * n, Z.shape[1]))
     idx = lambda v, k: stokes_block_index(nt, k // nt, v, k % nt)  # noqa: E731
     for a in range(n):
         for b in range(n):
@@ -368,7 +400,11 @@ def get_fe_time_weights_stokes(type_, r, time_step_size, n_timesteps_at_once=1):
                     if not (iv == 1 and jv == 1):
                         Alpha[idx(iv, a), idx(jv, b)] = A[a, b]
             Beta[idx(0, a), idx(0, b)] = B[a, b]
-    return Alpha, Beta
+        Gamma[idx(0, a), :] = G[a, :]
+        Zeta[idx(0, a), :] = Z[a, :]
+        if type_ == CGP:
+            Gamma[idx(1, a), :] = G[a, :]
+    return Alpha, Beta, Gamma, Zeta
 
 
 class StokesMatrixFreeOperator:

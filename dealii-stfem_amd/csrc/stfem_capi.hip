@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -518,12 +519,24 @@ template <class PR> static int ensure_metric(stfem_ctx *c, bool use_lap, bool us
             v[3 * o + 2] = c->lower[2] + c->h[2] * k;
           }
     }
-    if (hipMalloc(&c->d_vertices, v.size() * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
-    HIP_TRY(hipMemcpy(c->d_vertices, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    // (both uploads complete before the context sees either pointer: a failure half way must not
+    // leave d_vertices set and d_rule missing, the next call would launch with a null rule)
     std::vector<double> rule(c->tab.xq);
     rule.insert(rule.end(), c->tab.wq.begin(), c->tab.wq.end());
-    if (hipMalloc(&c->d_rule, rule.size() * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
-    HIP_TRY(hipMemcpy(c->d_rule, rule.data(), rule.size() * sizeof(double), hipMemcpyHostToDevice));
+    double *dv = nullptr, *dr = nullptr;
+    if (hipMalloc(&dv, v.size() * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+    if (hipMalloc(&dr, rule.size() * sizeof(double)) != hipSuccess) {
+      (void)hipFree(dv);
+      return STFEM_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemcpy(dv, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dr, rule.data(), rule.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(dv);
+      (void)hipFree(dr);
+      return hip_fail(hipGetLastError(), "metric table upload");
+    }
+    c->d_vertices = dv;
+    c->d_rule = dr;
   }
   if (!c->d_metric && hipMalloc(&c->d_metric, nm * sizeof(real)) != hipSuccess)
     return STFEM_ERR_OUT_OF_MEMORY;
@@ -807,6 +820,72 @@ int stfem_diagonal(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *st
 {
   if (!c) return STFEM_ERR_INVALID_ARGUMENT;
   return c->prec ? diagonal_t<Prec32>(c, ms, ls, diag, stream) : diagonal_t<Prec64>(c, ms, ls, diag, stream);
+}
+
+extern "C++" {
+// d <- |d| > tol ? 1 / d : 1   (operators.h:1107-1109)
+template <typename T> __global__ __launch_bounds__(256) void invert_diagonal_kernel(int64_t n, T *d, T tol)
+{
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const T v = d[i];
+    d[i] = fabs(v) > tol ? T(1) / v : T(1);
+  }
+}
+// out = a * x + b * y
+template <typename T>
+__global__ __launch_bounds__(256) void lincomb_kernel(int64_t n, T a, const T *x, T b, const T *y, T *out)
+{
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    out[i] = a * x[i] + b * y[i];
+}
+template <typename T> static int invert_diagonal(stfem_ctx *c, void *d, hipStream_t st)
+{
+  const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 4096);
+  hipLaunchKernelGGL(invert_diagonal_kernel<T>, dim3(grid), dim3(256), 0, st, c->ndofs, static_cast<T *>(d),
+                     std::sqrt(std::numeric_limits<T>::epsilon()));
+  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+} // extern "C++"
+
+int stfem_diagonal_inverse(stfem_ctx *c, double ms, double ls, stfem_vec *diag, void *stream)
+{
+  const int rc = stfem_diagonal(c, ms, ls, diag, stream);
+  if (rc != STFEM_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->prec ? invert_diagonal<float>(c, diag->blk[0], st) : invert_diagonal<double>(c, diag->blk[0], st);
+}
+
+int stfem_st_diagonal(stfem_ctx *c, int n, const double *alpha, const double *beta, int inverse, stfem_vec *diag,
+                      void *stream)
+{
+  if (!c || !alpha || !beta || !diag || n < 1 || diag->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (diag->nb != n) return STFEM_ERR_SHAPE_MISMATCH;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // diag K and diag M (or their guarded inverses) once, then one linear combination per block
+  stfem_vec *dk = nullptr, *dm = nullptr;
+  int rc = stfem_vector_create(c, 1, &dk);
+  if (rc == STFEM_OK) rc = stfem_vector_create(c, 1, &dm);
+  if (rc == STFEM_OK) rc = inverse ? stfem_diagonal_inverse(c, 0.0, 1.0, dk, stream) : stfem_diagonal(c, 0.0, 1.0, dk, stream);
+  if (rc == STFEM_OK) rc = inverse ? stfem_diagonal_inverse(c, 1.0, 0.0, dm, stream) : stfem_diagonal(c, 1.0, 0.0, dm, stream);
+  const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 4096);
+  for (int i = 0; i < n && rc == STFEM_OK; ++i) {
+    const double a = inverse ? 1.0 / alpha[size_t(i) * n + i] : alpha[size_t(i) * n + i];
+    const double b = inverse ? 1.0 / beta[size_t(i) * n + i] : beta[size_t(i) * n + i];
+    if (c->prec)
+      hipLaunchKernelGGL(lincomb_kernel<float>, dim3(grid), dim3(256), 0, st, c->ndofs, float(a),
+                         static_cast<const float *>(dk->blk[0]), float(b), static_cast<const float *>(dm->blk[0]),
+                         static_cast<float *>(diag->blk[i]));
+    else
+      hipLaunchKernelGGL(lincomb_kernel<double>, dim3(grid), dim3(256), 0, st, c->ndofs, a,
+                         static_cast<const double *>(dk->blk[0]), b, static_cast<const double *>(dm->blk[0]),
+                         static_cast<double *>(diag->blk[i]));
+    if (hipGetLastError() != hipSuccess) rc = STFEM_ERR_HIP;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess && rc == STFEM_OK) rc = STFEM_ERR_HIP; // the temporaries go away below
+  stfem_vector_destroy(dk);
+  stfem_vector_destroy(dm);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------ BLAS-1 / halo

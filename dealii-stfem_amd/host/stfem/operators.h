@@ -58,12 +58,17 @@ public:
   }
 
   // operators.h:1060-1087; one value per cell, or per (cell, quadrature point)
+  // Both coefficients are filled where both scalings are nonzero (1071-1085).  NB: the coefficient tables
+  // live on the shared Context (one MatrixFree), not per operator as in the reference: K and M built on
+  // one context see each other's coefficients, which is what tests/tp_01.cc:141-150 sets up anyway
+  // (coefficient on K only, whose mass scaling is 0).
   void evaluate_coefficient(const std::vector<double> &values)
   {
     const size_t ncells = size_t(stfem_n_cells(ctx_->h));
     const int layout = values.size() == ncells ? 1 : 2;
-    const int which = laplace_matrix_scaling != 0.0 ? 1 : 0;
-    check(stfem_set_coefficient(ctx_->h, which, layout, values.data()), "evaluate_coefficient");
+    if (mass_matrix_scaling != 0.0) check(stfem_set_coefficient(ctx_->h, 0, layout, values.data()), "evaluate_coefficient");
+    if (laplace_matrix_scaling != 0.0)
+      check(stfem_set_coefficient(ctx_->h, 1, layout, values.data()), "evaluate_coefficient");
   }
 
   unsigned long long m() const { return (unsigned long long)stfem_n_dofs(ctx_->h); }
@@ -75,6 +80,16 @@ public:
     d.reinit(ctx_);
     check(stfem_diagonal(ctx_->h, mass_matrix_scaling, laplace_matrix_scaling, d.handle(), stream),
           "get_matrix_diagonal");
+    return d;
+  }
+
+  // operators.h:1041-1045, 1106-1109: 1 / d where |d| > sqrt(eps), 1 elsewhere
+  VectorType get_matrix_diagonal_inverse(void *stream = nullptr) const
+  {
+    VectorType d;
+    d.reinit(ctx_);
+    check(stfem_diagonal_inverse(ctx_->h, mass_matrix_scaling, laplace_matrix_scaling, d.handle(), stream),
+          "get_matrix_diagonal_inverse");
     return d;
   }
 
@@ -154,7 +169,28 @@ public:
     vec.reinit(K.context(), Alpha.m());
   }
 
+  // operators.h:613-623: block i = Alpha(i,i) diag K + Beta(i,i) diag M
+  BlockVectorType get_matrix_diagonal(void *stream = nullptr) const { return diagonal(0, stream); }
+  // operators.h:625-637 (as the reference combines it): 1/Alpha(i,i) (diag K)^-1 + 1/Beta(i,i) (diag M)^-1
+  BlockVectorType get_matrix_diagonal_inverse(void *stream = nullptr) const { return diagonal(1, stream); }
+  // operators.h:384-388: linear operator, nothing to linearise around
+  virtual void set_data(const BlockVectorType &) const {}
+
 private:
+  BlockVectorType diagonal(int inverse, void *stream) const
+  {
+    if (Alpha.m() != Alpha.n()) throw std::invalid_argument("diagonal of a non-square system");
+    BlockVectorType d;
+    d.reinit(K.context(), Alpha.m());
+    std::vector<double> a(size_t(Alpha.m()) * Alpha.n()), b(a.size());
+    for (size_t i = 0; i < a.size(); ++i) {
+      a[i] = double(Alpha.data()[i]);
+      b[i] = double(Beta.data()[i]);
+    }
+    check(stfem_st_diagonal(K.context()->h, int(Alpha.m()), a.data(), b.data(), inverse, d.handle(), stream),
+          "SystemMatrix::get_matrix_diagonal");
+    return d;
+  }
   void apply(BlockVectorType &dst, const BlockVectorType &src, int transpose, int add, void *stream) const
   {
     // the C-ABI takes the temporal matrices in double whatever the operator's Number is
@@ -172,6 +208,87 @@ private:
   const FullMatrix<Number> &Alpha;
   const FullMatrix<Number> &Beta;
   bool alpha_is_zero, beta_is_zero;
+};
+
+// include/operators.h:1953-2050 PDE<>: the nonlinear-solver face of an operator.  residual = rhs - form(src);
+// form falls back to vmult for operators without one (internal::has_form, 1999-2004); vmult applies the
+// Jacobian operator (the same object unless given separately).
+template <int dim, typename Number, typename PDEOperator, typename JacOperator = PDEOperator> class PDE {
+  using BlockVectorType = BlockVectorT<Number>;
+
+  template <typename Op, typename = void> struct has_form : std::false_type {};
+  template <typename Op>
+  struct has_form<Op, std::void_t<decltype(std::declval<const Op &>().form(std::declval<BlockVectorType &>(),
+                                                                          std::declval<const BlockVectorType &>()))>>
+    : std::true_type {};
+
+public:
+  void init(const PDEOperator &pde_operator_, const BlockVectorType &rhs_)
+  {
+    pde_operator = &pde_operator_;
+    jac_operator = &pde_operator_;
+    rhs = &rhs_;
+  }
+  void init(const PDEOperator &pde_operator_, const JacOperator &jac_operator_, const BlockVectorType &rhs_)
+  {
+    pde_operator = &pde_operator_;
+    jac_operator = &jac_operator_;
+    rhs = &rhs_;
+  }
+  void set_rhs(const BlockVectorType &rhs_) const { rhs = &rhs_; }
+  void set_data(const BlockVectorType &data) const
+  {
+    pde_operator->set_data(data);
+    if (static_cast<const void *>(pde_operator) != static_cast<const void *>(jac_operator)) jac_operator->set_data(data);
+  }
+  void residual(BlockVectorType &dst, const BlockVectorType &src, const BlockVectorType &rhs_) const
+  {
+    rhs = &rhs_;
+    residual(dst, src);
+  }
+  // rhs - form(src): dst = -form(src) + rhs through the block BLAS-1 of the boundary
+  void residual(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    form(dst, src);
+    const unsigned n = dst.n_blocks();
+    FullMatrix<Number> minus_two(n, n), one(n, n);
+    for (unsigned i = 0; i < n; ++i) {
+      minus_two(i, i) = Number(-2); // dst += -2 dst  ->  -form
+      one(i, i) = Number(1);
+    }
+    BlockVectorType tmp;
+    tmp.reinit(dst.context(), n);
+    tensorproduct_add_impl(dst.context(), tmp, one, dst);       // tmp = form
+    tensorproduct_add_impl(dst.context(), dst, minus_two, tmp); // dst = form - 2 form
+    tensorproduct_add_impl(dst.context(), dst, one, *rhs);      // dst = rhs - form
+  }
+  void form(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    if constexpr (has_form<PDEOperator>::value) pde_operator->form(dst, src);
+    else pde_operator->vmult(dst, src);
+  }
+  void vmult(BlockVectorType &dst, const BlockVectorType &src) const { jac_operator->vmult(dst, src); }
+  template <typename Number2> void initialize_dof_vector(VectorT<Number2> &vec, unsigned i = 0) const
+  {
+    pde_operator->initialize_dof_vector(vec, i);
+  }
+  template <typename Number2> void initialize_dof_vector(BlockVectorT<Number2> &vec) const
+  {
+    pde_operator->initialize_dof_vector(vec);
+  }
+
+private:
+  static void tensorproduct_add_impl(const std::shared_ptr<Context> &ctx, BlockVectorType &c, const FullMatrix<Number> &A,
+                                     const BlockVectorType &b)
+  {
+    std::vector<double> a(size_t(A.m()) * A.n());
+    for (size_t i = 0; i < a.size(); ++i) a[i] = double(A.data()[i]);
+    check(stfem_tensorproduct_add(ctx->h, int(A.m()), int(A.n()), a.data(), c.handle(), b.handle(), nullptr),
+          "PDE::residual");
+  }
+  mutable const BlockVectorType *rhs = nullptr;
+  const PDEOperator *pde_operator = nullptr;
+  const JacOperator *jac_operator = nullptr;
 };
 
 // operators.h:211-283 tensorproduct_add: c_i += A(i,j) b_j

@@ -37,24 +37,33 @@ private:
   bool variable_major_;
 };
 
-// fe_time.h:1242-1285: {Alpha, Beta} in the (variable, time dof) block structure (the rhs
-// matrices Gamma, Zeta of the reference's return value are not needed by vmult)
+// fe_time.h:1242-1285: {Alpha, Beta, Gamma, Zeta} in the (variable, time dof) block structure: the
+// scalar matrices of get_fe_time_weights scattered over the two variables; no pressure-pressure
+// block in Alpha, only velocity-velocity in Beta; Gamma / Zeta (right-hand side) on the velocity
+// rows, Gamma for cG on the pressure rows too (1275-1282)
 template <typename Number>
-std::array<FullMatrix<Number>, 2> get_fe_time_weights_stokes(TimeStepType type, unsigned r, double time_step_size,
+std::array<FullMatrix<Number>, 4> get_fe_time_weights_stokes(TimeStepType type, unsigned r, double time_step_size,
                                                              unsigned n_timesteps_at_once = 1)
 {
   const auto tw = get_fe_time_weights<Number>(type, r, time_step_size, n_timesteps_at_once);
   const unsigned n = tw[0].m(), nt = n / n_timesteps_at_once;
   BlockSlice s(n_timesteps_at_once, 2, nt);
-  std::array<FullMatrix<Number>, 2> ret{{FullMatrix<Number>(2 * n, 2 * n), FullMatrix<Number>(2 * n, 2 * n)}};
+  std::array<FullMatrix<Number>, 4> ret{{FullMatrix<Number>(2 * n, 2 * n), FullMatrix<Number>(2 * n, 2 * n),
+                                         FullMatrix<Number>(2 * n, tw[2].n()), FullMatrix<Number>(2 * n, tw[3].n())}};
   auto idx = [&](unsigned v, unsigned k) { return s.index(k / nt, v, k % nt); };
-  for (unsigned a = 0; a < n; ++a)
+  for (unsigned a = 0; a < n; ++a) {
     for (unsigned b = 0; b < n; ++b) {
       for (unsigned iv = 0; iv < 2; ++iv)
         for (unsigned jv = 0; jv < 2; ++jv)
           if (!(iv == 1 && jv == 1)) ret[0](idx(iv, a), idx(jv, b)) = tw[0](a, b);
       ret[1](idx(0, a), idx(0, b)) = tw[1](a, b);
     }
+    for (unsigned q = 0; q < tw[2].n(); ++q) {
+      ret[2](idx(0, a), q) = tw[2](a, q);
+      if (type == TimeStepType::CGP) ret[2](idx(1, a), q) = tw[2](a, q);
+    }
+    for (unsigned q = 0; q < tw[3].n(); ++q) ret[3](idx(0, a), q) = tw[3](a, q);
+  }
   return ret;
 }
 

@@ -123,6 +123,7 @@ public:
     return h;
   }
   stfem_vec *handle() const { return v_.get(); }
+  const std::shared_ptr<Context> &context() const { return ctx_; }
 
 private:
   std::shared_ptr<Context> ctx_;

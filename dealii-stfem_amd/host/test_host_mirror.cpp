@@ -58,6 +58,32 @@ template <typename Number> int run(int argc, char **argv)
     rhs_matrix.vmult_slice(rhs, prev);
     rhs_matrix.vmult_slice_add(rhs, prev);
 
+    // the nonlinear-solver face (operators.h:1953-2050): residual = rhs - A x, vmult = Jacobian apply
+    PDE<3, Number, SystemN> pde;
+    pde.init(matrix, y); // rhs := y = A x  ->  residual(x) = 0, residual(0.5 x) = 0.5 A x
+    BlockVectorT<Number> res0, res1, half, yj;
+    for (auto *v : {&res0, &res1, &half, &yj}) pde.initialize_dof_vector(*v);
+    pde.residual(res0, x);
+    {
+      auto hh = hx;
+      for (auto &b : hh)
+        for (double &v : b) v *= 0.5;
+      half.copy_from_host(hh);
+    }
+    pde.residual(res1, half, y);
+    pde.vmult(yj, x);
+    // diagonals (operators.h:613-637, 1035-1045, 1106-1109)
+    const auto dst_diag = matrix.get_matrix_diagonal();
+    const auto dst_inv = matrix.get_matrix_diagonal_inverse();
+    BlockVectorT<Number> dk, dki;
+    dk.reinit(K_mf.context(), 1);
+    dki.reinit(K_mf.context(), 1);
+    {
+      const auto d = K_mf.get_matrix_diagonal(), di = K_mf.get_matrix_diagonal_inverse();
+      dk.copy_from_host({d.copy_to_host()});
+      dki.copy_from_host({di.copy_to_host()});
+    }
+
     // error behaviour: aliasing and shape mismatch must throw
     int thrown = 0;
     try { matrix.vmult(x, x); } catch (const Error &e) { thrown += e.status == STFEM_ERR_ALIAS; }
@@ -71,7 +97,10 @@ template <typename Number> int run(int argc, char **argv)
     std::fwrite(&n, sizeof n, 1, f);
     for (const auto *v : {&hx})
       for (const auto &b : *v) std::fwrite(b.data(), sizeof(double), n, f);
-    for (const auto &vec : {y.copy_to_host(), yT.copy_to_host(), rhs.copy_to_host()})
+    for (const auto &vec : {y.copy_to_host(), yT.copy_to_host(), rhs.copy_to_host(), res0.copy_to_host(), res1.copy_to_host(),
+                            yj.copy_to_host(), dst_diag.copy_to_host(), dst_inv.copy_to_host()})
+      for (const auto &b : vec) std::fwrite(b.data(), sizeof(double), n, f);
+    for (const auto &vec : {dk.copy_to_host(), dki.copy_to_host()})
       for (const auto &b : vec) std::fwrite(b.data(), sizeof(double), n, f);
     std::fclose(f);
     std::printf("m=%llu blocks=%llu exceptions=%d\n", matrix.m(), nb, thrown);

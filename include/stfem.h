@@ -122,6 +122,16 @@ int stfem_space_vmult(stfem_ctx *ctx, double mass_scaling, double laplace_scalin
  * of ms*M_c + ls*K_c into block 0 of diag; constrained rows are 0. */
 int stfem_diagonal(stfem_ctx *ctx, double mass_scaling, double laplace_scaling, stfem_vec *diag,
                    void *stream);
+/* get_matrix_diagonal_inverse (operators.h:1106-1109): 1 / d where |d| > sqrt(epsilon of the
+ * operator's Number), 1 elsewhere (constrained rows). */
+int stfem_diagonal_inverse(stfem_ctx *ctx, double mass_scaling, double laplace_scaling,
+                           stfem_vec *diag, void *stream);
+/* SystemMatrix::get_matrix_diagonal (operators.h:613-623): block i of diag =
+ * Alpha(i,i) * diag K + Beta(i,i) * diag M with K = MatrixFreeOperator(0,1), M = (1,0);
+ * inverse != 0: get_matrix_diagonal_inverse exactly as the reference combines it (633-637):
+ * 1/Alpha(i,i) * (diag K)^-1 + 1/Beta(i,i) * (diag M)^-1.  alpha, beta: n x n row-major. */
+int stfem_st_diagonal(stfem_ctx *ctx, int n, const double *alpha, const double *beta, int inverse,
+                      stfem_vec *diag, void *stream);
 
 /* Block BLAS-1 used around the operator (operators.h:211-283 tensorproduct_add;
  * LinearAlgebra::distributed::Vector::add / l2_norm / operator*).  Local to this rank:

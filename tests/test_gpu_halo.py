@@ -33,11 +33,13 @@ def stfem():
     (4, (4, 3, 4), 2, 0.15, "float"),
 ])
 def test_slab_exchange_on_one_gpu(stfem, oracle_mod, p, gnc, world, distort, number):
-    import torch
+    import ctypes
     dmod = importlib.import_module("dealii-stfem_amd.distributed")
     L = stfem.lib()
-    dev = torch.device("cuda", 0)
-    tdt = torch.float64 if number == "double" else torch.float32
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself uses (already loaded)
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    esz = 8 if number == "double" else 4
     tol = 1e-12 if number == "double" else 2e-5
     Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.01, 1)
     nb = Alpha.shape[0]
@@ -70,28 +72,32 @@ def test_slab_exchange_on_one_gpu(stfem, oracle_mod, p, gnc, world, distort, num
         src = stfem.BlockVector(ctx, nb).upload(X[:, lo:hi])  # owned + ghost plane, consistent
         dst = A.initialize_dof_vector()
         A.vmult(dst, src)
-        bufs = {k: torch.zeros(nb * plane, dtype=tdt, device=dev) for k in ("ts", "bs", "tr", "br")}
+        # packed-plane buffers (n_blocks planes each): device memory from the library itself
         nzl = p * (slab.z1 - slab.z0) + 1
-        ranks.append(dict(slab=slab, ctx=ctx, A=A, src=src, dst=dst, bufs=bufs, nzl=nzl, lo=lo, hi=hi))
+        assert nzl >= nb
+        hold = stfem.BlockVector(ctx, 4)
+        bufs = {k: hold.block_ptr(q) for q, k in enumerate(("ts", "bs", "tr", "br"))}
+        ranks.append(dict(slab=slab, ctx=ctx, A=A, src=src, dst=dst, bufs=bufs, hold=hold, nzl=nzl, lo=lo, hi=hi))
     for R in ranks:
         if R["slab"].has_upper:
-            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["ts"].data_ptr(), None) == 0
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["ts"], None) == 0
         if R["slab"].has_lower:
-            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["bs"].data_ptr(), None) == 0
-    torch.cuda.synchronize()
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["bs"], None) == 0
+    assert hip.hipDeviceSynchronize() == 0
     # the exchange (between GPUs: ncclSend / ncclRecv of exactly these buffers)
+    D2D = 3  # hipMemcpyDeviceToDevice
     for r, R in enumerate(ranks):
         if R["slab"].has_upper:
-            ranks[r + 1]["bufs"]["br"].copy_(R["bufs"]["ts"])
+            assert hip.hipMemcpy(ranks[r + 1]["bufs"]["br"], R["bufs"]["ts"], nb * plane * esz, D2D) == 0
         if R["slab"].has_lower:
-            ranks[r - 1]["bufs"]["tr"].copy_(R["bufs"]["bs"])
-    torch.cuda.synchronize()
+            assert hip.hipMemcpy(ranks[r - 1]["bufs"]["tr"], R["bufs"]["bs"], nb * plane * esz, D2D) == 0
+    assert hip.hipDeviceSynchronize() == 0
     for R in ranks:
         if R["slab"].has_upper:
-            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["tr"].data_ptr(), 1, None) == 0
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["tr"], 1, None) == 0
         if R["slab"].has_lower:
-            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["br"].data_ptr(), 1, None) == 0
-    torch.cuda.synchronize()
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["br"], 1, None) == 0
+    assert hip.hipDeviceSynchronize() == 0
     for R in ranks:
         Y = R["dst"].download()
         assert rel(Y, Ygpu[:, R["lo"]:R["hi"]]) < tol  # owner and ghost copies of every interface plane agree
@@ -99,6 +105,6 @@ def test_slab_exchange_on_one_gpu(stfem, oracle_mod, p, gnc, world, distort, num
 
     # argument checks of the pack / unpack entry points (include/stfem.h)
     R = ranks[0]
-    assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"], R["bufs"]["ts"].data_ptr(), None) != 0
-    assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, -1, R["bufs"]["ts"].data_ptr(), 1, None) != 0
+    assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"], R["bufs"]["ts"], None) != 0
+    assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, -1, R["bufs"]["ts"], 1, None) != 0
     assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, None, None) != 0

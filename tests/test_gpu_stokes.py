@@ -67,7 +67,7 @@ def test_stokes_vs_oracle_two_steps(variable_major, stfem):
     orc = oracle.StokesOracle(nc, verts, mask, nu)
     assert (op.n_velocity, op.n_pressure) == (orc.n_u, orc.n_p)
     ns, r = 2, 2
-    Alpha_vm, Beta_vm = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 16, ns)
+    Alpha_vm, Beta_vm, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 16, ns)
     nt = r
     nb = 2 * nt * ns
     # permute to the requested block ordering

@@ -38,8 +38,10 @@ def test_cpp_caller_matches_oracle(case, number, tmp_path, oracle_mod):
     assert "exceptions=3" in res.stdout
     raw = np.fromfile(out, dtype=np.uint64, count=2)
     nb, n = int(raw[0]), int(raw[1])
-    data = np.fromfile(out, dtype=np.float64, offset=16).reshape(4, nb, n)
-    X, Y, YT, RHS = data
+    flat = np.fromfile(out, dtype=np.float64, offset=16)
+    data = flat[:9 * nb * n].reshape(9, nb, n)
+    X, Y, YT, RHS, RES0, RES1, YJ, DIAG, DINV = data
+    DK, DKI = flat[9 * nb * n:].reshape(2, n)
     Alpha, Beta, Gamma, Zeta = stfem.get_fe_time_weights(ttype, r, 1.0 / 32, ns)
     verts = stfem.mesh_vertices(nc)
     orc = oracle_mod.Oracle(p, nc, verts, 63)
@@ -49,6 +51,18 @@ def test_cpp_caller_matches_oracle(case, number, tmp_path, oracle_mod):
     g, z = (Gamma, Zeta) if ttype == 0 else (np.zeros_like(Gamma), Gamma)  # tests/tp_01.cc:160-166
     ref = orc.st_vmult(g, z, X[:1])
     assert rel(RHS, 2 * ref) < tol  # vmult_slice followed by vmult_slice_add
+    # PDE<> (operators.h:1953-2050): residual = rhs - form, vmult = Jacobian
+    assert np.linalg.norm(RES0) < 10 * tol * np.linalg.norm(Y)
+    assert rel(RES1, 0.5 * Y) < 10 * tol
+    assert rel(YJ, Y) < tol
+    # diagonals: spatial (1092-1110) and space-time (613-637, combined exactly as the reference does)
+    dK, dM = orc.diagonal(0.0, 1.0), orc.diagonal(1.0, 0.0)
+    guard = np.sqrt(np.finfo(np.float64 if number == "double" else np.float32).eps)
+    inv = lambda d: np.where(np.abs(d) > guard, 1.0 / np.where(d == 0, 1.0, d), 1.0)  # noqa: E731
+    assert rel(DK, dK) < tol and rel(DKI, inv(dK)) < 10 * tol
+    for i in range(nb):
+        assert rel(DIAG[i], Alpha[i, i] * dK + Beta[i, i] * dM) < tol
+        assert rel(DINV[i], inv(dK) / Alpha[i, i] + inv(dM) / Beta[i, i]) < 10 * tol
 
 
 @pytest.mark.gpu
@@ -77,7 +91,7 @@ def test_cpp_stokes_caller_matches_oracle(case, tmp_path):
         Y.append(raw[off:off + 8 * n].view(np.float64).copy()); off += 8 * n
     verts = stfem.mesh_vertices(nc, distort=0.1, seed=99)
     orc = oracle.StokesOracle(nc, verts, 63, nu)
-    Alpha, Beta = stfem.get_fe_time_weights_stokes(ttype, r, 1.0 / 32, ns)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(ttype, r, 1.0 / 32, ns)
     nt = r if ttype == 0 else r + 1
     ref = orc.st_vmult(Alpha, Beta, ns, nt, X)
     for b in range(nb):

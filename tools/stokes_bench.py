@@ -13,7 +13,7 @@ stfem = importlib.import_module("dealii-stfem_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 r = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 op = stfem.StokesMatrixFreeOperator((N, N, N), viscosity=1.0)
-Alpha, Beta = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 64, 1)
+Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 64, 1)
 nt = r
 rng = np.random.default_rng(0)
 src, dst = [None] * (2 * nt), [None] * (2 * nt)
