@@ -14,7 +14,7 @@ _LIB = os.path.join(_HERE, "libstfem_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("stfem_oracle.c", "stfem_oracle_stokes.c", "stfem_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("stfem_oracle.c", "stfem_oracle_stokes.c", "stfem_cpu_baseline.c", "stfem_oracle.h")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libstfem_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -64,6 +64,8 @@ def lib():
         L.stfo_stokes_n_pressure.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.stfo_stokes_apply.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
+        L.stfb_st_vmult.argtypes = [C.c_int, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.c_int, _dp, _dp,
+                                    C.POINTER(_dp), C.POINTER(_dp), _dp, C.c_int]
         # default thread count: the visible CPUs, but never more than 16 (a GPU box advertises 256
         # logical CPUs and grants far fewer; oversubscribed libgomp threads spin)
         L.stfo_set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
@@ -261,3 +263,34 @@ class StokesOracle:
                         if abs(Beta[j, i]) > eps10:
                             dst[j] += Beta[j, i] * mu.reshape(-1)
         return dst
+
+
+# ---- CPU baseline (stfem_cpu_baseline.c): the reference's structure the way MatrixFree runs it
+
+class CpuBaseline:
+    """SystemMatrix::vmult on a Cartesian box: 2 n_blocks spatial cell loops + axpys
+    (include/operators.h:536-559), Cartesian-compressed geometry, SIMD across cells, OpenMP."""
+
+    def __init__(self, p, ncell, lower=(0, 0, 0), upper=(1, 1, 1), dirichlet_mask=63, threads=0):
+        self.p = p
+        self.nc = (C.c_int * 3)(*ncell)
+        self.lower = np.array(lower, dtype=np.float64)
+        self.upper = np.array(upper, dtype=np.float64)
+        self.mask = dirichlet_mask
+        self.threads = threads or max(1, min(64, len(os.sched_getaffinity(0))))
+        self.n_dofs = int(np.prod([p * n + 1 for n in ncell]))
+        self._tmp = np.empty(self.n_dofs)
+
+    def st_vmult(self, Alpha, Beta, X, Y=None):
+        nb = Alpha.shape[0]
+        assert Alpha.shape == (nb, nb) and X.shape == (nb, self.n_dofs)
+        A = np.ascontiguousarray(Alpha, dtype=np.float64)
+        B = np.ascontiguousarray(Beta, dtype=np.float64)
+        if Y is None:
+            Y = np.empty_like(X)
+        src = (_dp * nb)(*[_p(X[b]) for b in range(nb)])
+        dst = (_dp * nb)(*[_p(Y[b]) for b in range(nb)])
+        rc = lib().stfb_st_vmult(self.p, self.nc, _p(self.lower), _p(self.upper), self.mask, nb, _p(A), _p(B),
+                                 src, dst, _p(self._tmp), self.threads)
+        assert rc == 0
+        return Y
