@@ -243,11 +243,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(ctx.last_kernel_name)
                          if (world, n, p, r, args.distort, args.number) == (1, 72, 4, 2, 0.0, "double") else None,
+                         "traffic_source": "profiles/latest/traffic.json: rocprofv3 --pmc passes of this command "
+                                           "(FETCH_SIZE x 2 + WRITE_SIZE), committed, not measured in this run",
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(stfem, p, r, args.cpu_cells or args.cells,
-                                               max(1, len(os.sched_getaffinity(0))))
+                                               max(1, min(16, len(os.sched_getaffinity(0)))))  # a 1-GPU box grants 16 cores
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -43,9 +43,10 @@ try:
         calls = min(n for (_, n) in per["FETCH_SIZE"].values())
         fetch = sum(s for (s, _) in per["FETCH_SIZE"].values()) / calls
         write = sum(s for (s, _) in per["WRITE_SIZE"].values()) / calls
-        kern = "st_sweep_cart_tile" if any("cart_tile" in k for k in per["FETCH_SIZE"]) else "st_sweep_cart_atomic"
+        kern = ("st_sweep_pencil" if any("sweep_pencil" in k for k in per["FETCH_SIZE"]) else
+                "st_sweep_cart_tile" if any("cart_tile" in k for k in per["FETCH_SIZE"]) else "st_sweep_cart_atomic")
         json.dump({"kernel": kern, "fetch_kb_per_vmult": fetch, "write_kb_per_vmult": write,
-                   "note": "sum over the kernels of one stfem_st_vmult (2 sweep colour launches + fix-up)"},
+                   "note": "sum over the kernels of one stfem_st_vmult (sweep launch(es) + fix-up)"},
                   open(os.path.join(d, "traffic.json"), "w"), indent=1)
         print("traffic.json:", fetch, write)
 except Exception as e:  # noqa
