@@ -5,11 +5,20 @@
  * apply.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may call it.  The product path (dealii-stfem_amd/csrc) never links it.
  *
- * Parity status: the vmult result itself is "parity unpinned" by the reference
- * (it ships no golden vmult vector and deal.II, which holds the arithmetic, is
- * absent from /root/reference and from this image).  What IS pinned:
- *   - the temporal matrices against the reference's tests/tp_02.output,
- *   - K/M against an independent numpy dense assembly (tests/golden/),
+ * Parity status: the reference ships no golden vmult VECTOR (and deal.II, which
+ * holds the arithmetic, is absent from /root/reference and from this image), but
+ * everything the vmult is built from is pinned by reference-held numbers:
+ *   - the temporal matrices (scalar and Stokes block form) against the reference's
+ *     tests/tp_02.output, the BlockSlice tables against tests/tp04.output,
+ *   - the spatial ingredients (shape tables, Gauss rule, scalings, constraint
+ *     handling) in absolute terms: tests/test_tp01_reference.py re-derives the
+ *     error columns of the reference's 2D convergence study tests/tp_01.output
+ *     (dG(1), dG(2), cG(2), cG(3); two refinements each) to the printed digits
+ *     from the 1D matrices of these tables, and shows that this oracle's 3D
+ *     K and M on Cartesian meshes are exactly their Kronecker products,
+ *   - K/M on general (MappingQ1) meshes and with per-point coefficients against
+ *     an independent numpy dense assembly (tests/golden/): the one part no
+ *     reference-held number reaches,
  *   - the reference's own method of tests/tp_05dgp_support.cc:132-151
  *     (matrix-free apply == assembled matrix apply per unit vector).
  *

@@ -1,0 +1,237 @@
+"""Pins the oracle's spatial ingredients to ABSOLUTE numbers the reference itself holds.
+
+tests/tp_01.output (committed as the data golden tests/golden/tp_01.output) is the reference's
+space-time convergence study of the heat equation in 2D: errors |u_h - u| in L-infinity(L-infinity),
+L2(L2) and L2(H1-semi) to six digits for u = sin(2 pi t) sin(2 pi x) sin(2 pi y), FE_Q(k+1) in
+space, dG(k) / cG(k) in time, two time steps per solve.  Nothing else the reference ships reaches
+its spatial operator with an absolute number (deal.II is not available here, so its FGMRES +
+multigrid solver cannot be run: every slab system is solved directly instead, which changes the
+result by the solver tolerance 1e-12 only).
+
+This test re-derives those rows with the ORACLE's ingredients and the reference's recipe:
+  tests/tp_01.cc:76-119      FE_Q(k+1), QGauss(k+2), zero Dirichlet, K = (0,1), M = (1,0),
+                             tau = 2^-(refinement+1) (unit square, one subdivision)
+  tests/tp_01.cc:160-166     rhs_uK / rhs_uM (cG: Gamma, Zeta; dG: 0, Gamma)
+  include/time_integrators.h:85-120   assemble_force (time quadrature of the source term)
+  include/time_integrators.h:300-321  one solve per slab of n_timesteps_at_once steps
+  include/exact_solution.h:27-81      exact solution and source term
+  include/exact_solution.h:503-649    ErrorCalculator (QGauss(k+1) in time and per direction in space)
+  tests/tp_01.cc:404-427     u_h(t) from the temporal Lagrange basis
+with the 2D operators formed as Kronecker products of the 1D mass / stiffness matrices that the
+oracle's shape tables and Gauss rule give: M = M1 (x) M1, K = K1 (x) M1 + M1 (x) K1.  The second
+test closes the chain to the 3D operator the HIP kernels are compared with: on a Cartesian mesh the
+oracle's dense 3D K and M (unit-vector method, tests/tp_05dgp_support.cc:140-149) are exactly the
+Kronecker products of the same 1D matrices.  So the reference-held error columns pin the shape
+tables, quadrature, scalings, constraint handling and temporal matrices the oracle's (and hence
+the GPU's) vmult is built from."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def lagrange_eval(nodes, x):
+    """values L[q, a] = l_a(x_q) and derivatives of the Lagrange basis through `nodes`"""
+    nodes = np.asarray(nodes, dtype=float)
+    x = np.atleast_1d(np.asarray(x, dtype=float))
+    n = len(nodes)
+    L = np.ones((len(x), n))
+    dL = np.zeros((len(x), n))
+    for a in range(n):
+        for m in range(n):
+            if m != a:
+                L[:, a] *= (x - nodes[m]) / (nodes[a] - nodes[m])
+        for m in range(n):
+            if m == a:
+                continue
+            t = np.full(len(x), 1.0 / (nodes[a] - nodes[m]))
+            for l in range(n):
+                if l != a and l != m:
+                    t *= (x - nodes[l]) / (nodes[a] - nodes[l])
+            dL[:, a] += t
+    return L, dL
+
+
+def matrices_1d(o, p, n):
+    """global 1D mass and stiffness matrices of FE_Q(p) on n cells of [0, 1], QGauss(p + 1)"""
+    S, D = o.shape_tables(p)  # S[q, a], D[q, a]: values / reference derivatives at the Gauss points
+    _, w = o.gauss(p + 1)
+    h = 1.0 / n
+    Mc = h * (S.T * w) @ S
+    Kc = (1.0 / h) * (D.T * w) @ D
+    nd = p * n + 1
+    M = np.zeros((nd, nd))
+    K = np.zeros((nd, nd))
+    for c in range(n):
+        sl = slice(p * c, p * c + p + 1)
+        M[sl, sl] += Mc
+        K[sl, sl] += Kc
+    return M, K
+
+
+def convergence_row(o, ttype, k, refinement, nsteps=2, frequency=1.0):
+    """(L-inf L-inf, L2 L2, L2 H1-semi) of one row of the reference's convergence table"""
+    p = k + 1
+    n = 2 ** refinement
+    h = 1.0 / n
+    nd = p * n + 1
+    tau = 2.0 ** -(refinement + 1)  # tests/tp_01.cc:106-109 with spc_step = 1
+    M1, K1 = matrices_1d(o, p, n)
+    M = np.kron(M1, M1)
+    K = np.kron(K1, M1) + np.kron(M1, K1)
+    idx = np.arange(nd * nd).reshape(nd, nd)
+    free = idx[1:-1, 1:-1].ravel()
+    Kf, Mf = K[np.ix_(free, free)], M[np.ix_(free, free)]
+
+    A, B, G, Z = o.time_weights(ttype, k, tau, nsteps)
+    A1, _, G1, _ = o.time_weights(ttype, k, tau, 1)
+    ntd = k if ttype == o.CGP else k + 1
+    nb = ntd * nsteps
+    sysmat = np.kron(A, Kf) + np.kron(B, Mf)
+    rK, rM = (G, Z) if ttype == o.CGP else (np.zeros_like(G), G)  # tests/tp_01.cc:160-166
+
+    # nodes (for the load vector and the errors)
+    gll = o.gauss_lobatto(p + 1)
+    xq, wq = o.gauss(p + 1)  # QGauss(fe degree + 1): operator and load-vector quadrature
+    S, _ = o.shape_tables(p)
+    two_pi_f = 2 * np.pi * frequency
+
+    def load_vector(t):
+        """VectorTools::create_right_hand_side with RHSFunction (exact_solution.h:62-81)"""
+        amp = 2 * (two_pi_f ** 2) * np.sin(two_pi_f * t) + two_pi_f * np.cos(two_pi_f * t)
+        f1 = np.zeros(nd)  # int sin(2 pi f x) phi_i dx: the source is a product in x and y
+        for c in range(n):
+            xs = h * (c + xq)
+            f1[p * c:p * c + p + 1] += h * (S.T * wq) @ np.sin(two_pi_f * xs)
+        return amp * np.outer(f1, f1).ravel()[free]
+
+    tq_int = o.gauss_radau_right(k + 1) if ttype == o.DG else o.gauss_lobatto(k + 1)  # fe_time.cc:152-161
+    # error evaluation: QGauss(k + 1) in time and per spatial direction (exact_solution.h:524-526)
+    et, ewt = o.gauss(k + 1)
+    ex, ewx = o.gauss(k + 1)
+    Ltime, _ = lagrange_eval(tq_int, et)
+    E, dE = lagrange_eval(gll, ex)  # spatial basis at the error quadrature points (reference cell)
+
+    def spatial_errors(u_full, t):
+        U = u_full.reshape(nd, nd)  # [iy, ix]
+        l2 = h1 = 0.0
+        l8 = 0.0
+        for cy in range(n):
+            for cx in range(n):
+                loc = U[p * cy:p * cy + p + 1, p * cx:p * cx + p + 1]
+                uh = E @ loc @ E.T                     # [qy, qx]
+                ux = (E @ loc @ dE.T) / h
+                uy = (dE @ loc @ E.T) / h
+                X = h * (cx + ex)[None, :]
+                Y = h * (cy + ex)[:, None]
+                st = np.sin(two_pi_f * t)
+                ue = st * np.sin(two_pi_f * X) * np.sin(two_pi_f * Y)
+                uex = st * two_pi_f * np.cos(two_pi_f * X) * np.sin(two_pi_f * Y)
+                uey = st * two_pi_f * np.sin(two_pi_f * X) * np.cos(two_pi_f * Y)
+                W = h * h * np.outer(ewx, ewx)
+                l2 += np.sum(W * (uh - ue) ** 2)
+                h1 += np.sum(W * ((ux - uex) ** 2 + (uy - uey) ** 2))
+                l8 = max(l8, np.abs(uh - ue).max())
+        return l2, l8, h1
+
+    prev = np.zeros(len(free))  # interpolation of the exact solution at t = 0
+    time, acc_l2, acc_l8, acc_h1 = 0.0, 0.0, -1.0, 0.0
+    while time < 1.0 - 1e-12:
+        rhs = np.zeros(nb * len(free))
+        blk = lambda j: slice(j * len(free), (j + 1) * len(free))  # noqa: E731
+        for j in range(nb):
+            rhs[blk(j)] = rK[j, 0] * (Kf @ prev) + rM[j, 0] * (Mf @ prev)
+        for it in range(nsteps):  # assemble_force (time_integrators.h:85-120)
+            for j, xi in enumerate(tq_int):
+                F = load_vector(time + tau * it + tau * xi)
+                if ttype == o.DG:
+                    rhs[blk(it * ntd + j)] += A1[j, j] * F
+                elif j == 0:
+                    for i in range(ntd):
+                        rhs[blk(it * ntd + i)] += -G1[i, 0] * F
+                else:
+                    rhs[blk(it * ntd + j - 1)] += A1[j - 1, j - 1] * F
+        x = np.linalg.solve(sysmat, rhs).reshape(nb, len(free))
+        for it in range(nsteps):  # ErrorCalculator::evaluate_error
+            prev_it = prev if it == 0 else x[ntd * it - 1]
+            for q in range(k + 1):
+                if ttype == o.DG:
+                    uf = sum(Ltime[q, i] * x[it * ntd + i] for i in range(ntd))
+                else:
+                    uf = Ltime[q, 0] * prev_it + sum(Ltime[q, i] * x[it * ntd + i - 1] for i in range(1, k + 1))
+                full = np.zeros(nd * nd)
+                full[free] = uf
+                l2, l8, h1 = spatial_errors(full, time + tau * it + tau * et[q])
+                acc_l2 += tau * ewt[q] * l2
+                acc_h1 += tau * ewt[q] * h1
+                acc_l8 = max(acc_l8, l8)
+        prev = x[-1]
+        time += nsteps * tau
+    return acc_l8, np.sqrt(acc_l2), np.sqrt(acc_h1)
+
+
+def golden_tables(golden_dir):
+    """-> list of (k, t_dofs, rows) in file order; rows = [(cells, linf, l2, h1)]"""
+    tables = []
+    with open(os.path.join(golden_dir, "tp_01.output")) as f:
+        lines = f.read().splitlines()
+    for n, line in enumerate(lines):
+        m = re.match(r"^Convergence table k=(\d+)$", line)
+        if not m:
+            continue
+        rows = []
+        for r in lines[n + 2:n + 6]:
+            t = r.split()
+            if len(t) < 6 or not t[0].isdigit():
+                break
+            # cells s-dofs t-dofs st-dofs work Linf [rate] L2 [rate] H1 [rate]
+            vals = [v for v in t[5:] if re.match(r"^\d\.\d+e[-+]\d+$", v)]
+            rows.append((int(t[0]), int(t[2]), float(vals[0]), float(vals[1]), float(vals[2])))
+        tables.append((int(m.group(1)), rows))
+    return tables
+
+
+# the first run of the golden: tests/json/tf01.json (dG(k), two steps at once, k = 1..3);
+# the second: tests/json/tf02.json (cG(k), k = 2..4)
+CASES = [("DG", 1, 0), ("DG", 2, 1), ("CG", 2, 3), ("CG", 3, 4)]
+
+
+@pytest.mark.parametrize("kind,k,table", CASES)
+def test_heat_convergence_rows_of_tp01(oracle_mod, golden_dir, kind, k, table):
+    o = oracle_mod
+    tabs = golden_tables(golden_dir)
+    gk, rows = tabs[table]
+    ttype = o.DG if kind == "DG" else o.CGP
+    ntd = k + 1 if kind == "DG" else k
+    assert gk == k and rows[0][1] == 2 * ntd, (gk, rows[0])
+    for ref, (cells, _, g8, g2, gh) in zip((2, 3), rows[:2]):  # the first two refinements
+        assert cells == 4 ** ref
+        l8, l2, h1 = convergence_row(o, ttype, k, ref)
+        # to the printed digits (%.5e: half a unit of the sixth digit, plus the solver tolerance)
+        for name, got, gold in (("L2-L2", l2, g2), ("L2-H1", h1, gh), ("Linf", l8, g8)):
+            ulp = 10.0 ** (np.floor(np.log10(gold)) - 5)
+            assert abs(got - gold) <= 0.51 * ulp + 1e-9 * gold, (kind, k, ref, name, got, gold)
+
+
+@pytest.mark.parametrize("p,nc", [(2, (3, 2, 2)), (3, (2, 2, 2)), (4, (2, 1, 2))])
+def test_oracle_3d_operators_are_kronecker_products_of_the_same_1d_matrices(oracle_mod, p, nc):
+    """closes the chain: the oracle's 3D K, M on a Cartesian mesh = Kronecker products of the 1D
+    matrices that reproduce the reference's error tables above (anisotropic box: all scalings)"""
+    import importlib
+    o = oracle_mod
+    stfem = importlib.import_module("dealii-stfem_amd")
+    upper = (1.0, 0.75, 1.5)
+    verts = stfem.mesh_vertices(nc, (0, 0, 0), upper)
+    orc = o.Oracle(p, nc, verts, 0)  # no constraints: the full matrices
+    M3, K3 = orc.dense(mass=1.0), orc.dense(laplace=1.0)
+    m, kk = [], []
+    for d in range(3):
+        M1, K1 = matrices_1d(o, p, nc[d])
+        L = upper[d]
+        m.append(M1 * L)       # cells of size L / n instead of 1 / n
+        kk.append(K1 / L)
+    Mk = np.kron(m[2], np.kron(m[1], m[0]))
+    Kk = (np.kron(m[2], np.kron(m[1], kk[0])) + np.kron(m[2], np.kron(kk[1], m[0])) + np.kron(kk[2], np.kron(m[1], m[0])))
+    assert np.abs(M3 - Mk).max() <= 1e-13 * np.abs(Mk).max()
+    assert np.abs(K3 - Kk).max() <= 1e-12 * np.abs(Kk).max()
