@@ -178,7 +178,7 @@ def main():
             dist.recv(g, rank + 1)
             src_t[:, -plane:] = g
 
-    kernel_ms = []
+    kernel_ms, exchange_ms = [], []
 
     def step(record=False):
         if record:
@@ -190,6 +190,10 @@ def main():
             kernel_ms.append((e0, e1))
         if world > 1:
             dmod.sharded_vmult(slab, lambda: None, pack, unpack_add, bufs, dist)
+            if record:  # pack + RCCL send/recv + unpack-add of the interface planes
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record()
+                exchange_ms.append((e1, e2))
 
     for _ in range(args.warmup):
         step()
@@ -220,6 +224,7 @@ def main():
         total_dofs = own
     ms_per_step = 1e3 * elapsed / args.steps
     kms = sum(a.elapsed_time(b) for a, b in kernel_ms) / len(kernel_ms)
+    xms = sum(a.elapsed_time(b) for a, b in exchange_ms) / len(exchange_ms) if exchange_ms else 0.0
 
     if rank == 0:
         # 16 B per space-time DoF per vmult (8 B src read + 8 B dst write)
@@ -238,7 +243,10 @@ def main():
                                    + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else "")
                                    + (" = the BASELINE configs[2] mesh" if (global_nc, p, r, args.distort) == ((144, 144, 144), 4, 2, 0.15) else ""),
                        "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
-                       "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name},
+                       "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name,
+                       # rank 0, per step: the local cell sweep and the packed interface-plane exchange
+                       # (weak scaling loses exactly the second; no other communication on the path)
+                       "local_sweep_ms": kms, "exchange_ms": xms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(ctx.last_kernel_name)
