@@ -93,6 +93,12 @@ def main():
     ap.add_argument("--strong-cells", type=int, default=144)
     ap.add_argument("--number", choices=["double", "float"], default="double",
                     help="operator Number type: double (headline) or float (the reference's multigrid-level precision)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearsal of the N > 1 path on ONE GPU (all ranks share cuda:0, the interface planes "
+                         "are staged through host memory); timings of such a run mean nothing")
+    ap.add_argument("--check", action="store_true",
+                    help="N > 1: compare every rank's slab of the sharded vmult with a single-domain vmult of the "
+                         "whole mesh computed on the same GPU (small meshes only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU baseline mesh (0: as the GPU run)")
     args = ap.parse_args()
@@ -107,11 +113,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     stfem = importlib.import_module("dealii-stfem_amd")
     stfem.lib()
@@ -170,13 +181,39 @@ def main():
         rc = L.stfem_plane_unpack(ctx._h, dst._h, iz % nz_local, buf.data_ptr(), 1, stream())
         assert rc == 0, rc
 
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where exchanged buffers live
     if world > 1:  # make the src ghost plane consistent with its owner once (update_ghost_values)
         if slab.has_lower:
-            dist.send(src_t[:, :plane].contiguous(), rank - 1)
+            dist.send(src_t[:, :plane].contiguous().to(xdev), rank - 1)
         if slab.has_upper:
-            g = torch.empty((nb, plane), dtype=tdt, device=dev)
+            g = torch.empty((nb, plane), dtype=tdt, device=xdev)
             dist.recv(g, rank + 1)
-            src_t[:, -plane:] = g
+            src_t[:, -plane:] = g.to(dev)
+
+    class StagedDist:
+        """gloo rehearsal: the packed planes go through host memory around the same exchange calls"""
+        def __init__(self):
+            self.P2POp, self.isend, self.irecv = dist.P2POp, dist.isend, dist.irecv  # instance attributes: not bound
+            self.host = {k: torch.zeros(nb * plane, dtype=tdt) for k in bufs}
+
+        def batch_isend_irecv(self, ops):
+            torch.cuda.synchronize()
+            staged = []
+            for op in ops:
+                key = next(k for k, v in bufs.items() if v.data_ptr() == op.tensor.data_ptr())
+                if op.op == dist.isend:
+                    self.host[key].copy_(op.tensor)
+                staged.append(dist.P2POp(op.op, self.host[key], op.peer))
+            works = dist.batch_isend_irecv(staged)
+            for w in works:
+                w.wait()
+            for op in ops:
+                if op.op == dist.irecv:
+                    key = next(k for k, v in bufs.items() if v.data_ptr() == op.tensor.data_ptr())
+                    op.tensor.copy_(self.host[key])
+            return []
+
+    xdist = dist if args.backend == "nccl" else StagedDist()
 
     kernel_ms, exchange_ms = [], []
 
@@ -189,12 +226,32 @@ def main():
             e1.record()
             kernel_ms.append((e0, e1))
         if world > 1:
-            dmod.sharded_vmult(slab, lambda: None, pack, unpack_add, bufs, dist)
+            dmod.sharded_vmult(slab, lambda: None, pack, unpack_add, bufs, xdist)
             if record:  # pack + RCCL send/recv + unpack-add of the interface planes
                 e2 = torch.cuda.Event(enable_timing=True)
                 e2.record()
                 exchange_ms.append((e1, e2))
 
+    if args.check and world > 1:
+        import numpy as np
+        gctx = (stfem.MatrixFreeOperator(p, global_nc, vertices=stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, zext),
+                                                                                      args.distort, 5489), number=args.number)
+                if args.distort else
+                stfem.MatrixFreeOperator(p, global_nc, lower=(0, 0, 0), upper=(1, 1, zext), number=args.number))
+        Xg = np.random.default_rng(99).uniform(-1, 1, (nb, gctx.n_dofs))
+        lo, hi = p * slab.z0 * plane, (p * slab.z1 + 1) * plane
+        src_t.copy_(torch.from_numpy(Xg[:, lo:hi]).to(tdt))
+        step()
+        torch.cuda.synchronize()
+        gA = stfem.SystemMatrix(gctx, Alpha, Beta)
+        gdst = gA.initialize_dof_vector()
+        gA.vmult(gdst, stfem.BlockVector(gctx, nb).upload(Xg))
+        ref = gdst.download()[:, lo:hi]
+        got = dst_t.double().cpu().numpy()
+        err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        print(f"[check] rank {rank}: slab vs single-domain vmult rel-L2 = {err:.3e}", file=sys.stderr, flush=True)
+        assert err < (1e-12 if args.number == "double" else 2e-5), err
+        del gctx, gA, gdst
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -230,6 +287,8 @@ def main():
         # 16 B per space-time DoF per vmult (8 B src read + 8 B dst write)
         alg_bytes = 2.0 * esz * nb * ndofs  # fp64: 16 B per DoF; fp32: 8 B
         achieved = alg_bytes / (kms * 1e-3) / 1e9
+        traffic = (measured_traffic(ctx.last_kernel_name)
+                   if (world, n, p, r, args.distort, args.number) == (1, 72, 4, 2, 0.0, "double") else None)
         out = {
             "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s",
             "value": total_dofs * args.steps / elapsed,
@@ -249,10 +308,10 @@ def main():
                        "local_sweep_ms": kms, "exchange_ms": xms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(ctx.last_kernel_name)
-                         if (world, n, p, r, args.distort, args.number) == (1, 72, 4, 2, 0.0, "double") else None,
-                         "traffic_source": "profiles/latest/traffic.json: rocprofv3 --pmc passes of this command "
-                                           "(FETCH_SIZE x 2 + WRITE_SIZE), committed, not measured in this run",
+                         "traffic": traffic,
+                         "traffic_source": ("profiles/latest/traffic.json: rocprofv3 --pmc passes of this command "
+                                            "(FETCH_SIZE x 2 + WRITE_SIZE), committed, not measured in this run")
+                         if traffic is not None else None,
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

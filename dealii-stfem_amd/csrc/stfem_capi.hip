@@ -45,7 +45,7 @@ struct Prec64 {
   {
     return f64::launch_build_metric(p, nc, v, xq, wq, cl, ll, cm, ml, m, st);
   }
-  static const char *tile_name() { return "st_sweep_cart_tile<f64>"; }
+  static const char *tile_name(bool general) { return general ? "st_sweep_cart_tile<f64, stored metric>" : "st_sweep_cart_tile<f64>"; }
   static const char *atomic_name() { return "st_sweep_cart_atomic<f64>"; }
 };
 struct Prec32 {
@@ -73,7 +73,7 @@ struct Prec32 {
   {
     return f32::launch_build_metric(p, nc, v, xq, wq, cl, ll, cm, ml, m, st);
   }
-  static const char *tile_name() { return "st_sweep_cart_tile<f32>"; }
+  static const char *tile_name(bool general) { return general ? "st_sweep_cart_tile<f32, stored metric>" : "st_sweep_cart_tile<f32>"; }
   static const char *atomic_name() { return "st_sweep_cart_atomic<f32>"; }
 };
 
@@ -132,17 +132,6 @@ struct stfem_vec {
   bool owns = false;
   std::vector<void *> blk; // device arrays of the context's element type
 };
-
-namespace stfem {
-int tile_wg_per_cu(int p, int nbm)
-{
-  static const int forced = getenv("STFEM_TILE_WAVES") ? atoi(getenv("STFEM_TILE_WAVES")) : 0;
-  if (forced == 2 || forced == 3) return forced;
-  nbm = nbm <= 4 ? nbm : (nbm <= 6 ? 6 : 8);
-  (void)p;
-  return 2; // three fit (<= 168 VGPRs) for small p / few blocks, but measured no faster: the kernel is HBM-bound
-}
-} // namespace stfem
 
 extern "C" {
 
@@ -699,7 +688,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         }
         long long *tl_dev = c->d_timeline;
         rc = PR::tile(c->p, prm, tp, st);
-        c->last_kernel = PR::tile_name();
+        c->last_kernel = PR::tile_name(prm.metric != nullptr);
         if (tl_path && rc == 0) {
           HIP_TRY(hipStreamSynchronize(st));
           std::vector<long long> h(tl_n);

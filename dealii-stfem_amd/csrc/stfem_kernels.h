@@ -9,10 +9,6 @@ namespace stfem {
 constexpr int MAX_BLOCKS = 8; // temporal blocks handled by one launch (larger systems are tiled)
 constexpr int EO_N = 16;      // >= eo_size(5)
 
-// Waves per SIMD the fp64 tile kernel is compiled for (launch bounds): two.  The runtime keeps three
-// narrow-tile workgroups on a CU anyway when registers and LDS allow.  Builds with -DSTFEM_ALLOW_W3
-// also hold the 168-VGPR variants, selected with STFEM_TILE_WAVES=3 (experiments only).
-int tile_wg_per_cu(int p, int nbm);
 } // namespace stfem
 
 #define STFEM_REAL double

@@ -41,32 +41,26 @@ namespace {
 constexpr int tile_cells_per_wave(int p, int nbm)
 {
   const int cpw = (64 / (p + 1)) / nbm;
-#ifdef STFEM_TILE_CPW_MINUS1 // experiment: one cell less per wave (Q4 x 2 blocks: 40 000 B of LDS per workgroup)
-  return cpw > 1 ? cpw - 1 : cpw;
-#else
   return p * cpw + 1 > 64 ? 63 / p : cpw;
-#endif
 }
 // Tile rows of two wave-widths.  Every wave handles SX = 2 cell groups one after the other on the
 // fp64 Cartesian path: rows of 49 instead of 25 doubles for Q4 x 2 blocks, -20 % HBM fetch, half
 // the 32-byte partial writes, 7 % less time on cfg 1 (A/B on one box: 0.473 -> 0.440 ms).  Not
-// on the general path (metric-bound anyway; its fp64 instantiation fails parity with SX = 2, not
-// understood yet) and not in fp32 (128-VGPR budget).  -DSTFEM_TILE_WIDE_WG instead puts two waves
-// side by side (8-wave workgroup, one per CU): measured slower, its compute and memory phases no
-// longer overlap with a second workgroup's.
-#if defined(STFEM_TILE_WIDE_WG)
-constexpr int tile_wx(int p, int nbm) { return p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64 ? 2 : 1; }
-constexpr int tile_sx(int, int, bool) { return 1; }
-#elif (defined(STFEM_F32) && !defined(STFEM_F32_SX2)) || defined(STFEM_TILE_SX1)
-constexpr int tile_wx(int, int) { return 1; }
-constexpr int tile_sx(int, int, bool) { return 1; }
-#else
+// on the general path (metric-bound anyway; with SX = 2 its fp64 instantiation spills, and a spilled
+// destination of the asm-issued src prefetch is stored before its data has landed: that was the
+// parity failure of round 1, see load_plane_async) and not in fp32 (128-VGPR budget).  (Two waves
+// side by side in an 8-wave workgroup, one per CU, measured slower in round 1: its compute and memory
+// phases no longer overlap with a second workgroup's.)
 constexpr int tile_wx(int, int) { return 1; }
 constexpr int tile_sx(int p, int nbm, bool general)
 {
+#ifdef STFEM_F32
+  (void)p; (void)nbm; (void)general;
+  return 1;
+#else
   return (!general && nbm <= 3 && p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64) ? 2 : 1; // more blocks spill
-}
 #endif
+}
 
 constexpr int tile_threads(int p, int nbm) { return 256 * tile_wx(p, nbm); }
 constexpr int tile_min_blocks(int p, int nbm, int minw) { return minw / tile_wx(p, nbm) > 0 ? minw / tile_wx(p, nbm) : 1; }
@@ -175,13 +169,9 @@ __device__ __forceinline__ void load_plane_async(const real_t *s, int nx, real_t
       PA[y * N + x + 1] = v.y;
     }
     if (N & 1) {
-#ifdef STFEM_EXP_NO_TAIL_LOAD // timing experiment: one VMEM instruction less per row, same cache lines
-      PA[y * N + N - 1] = real_t(0);
-#else
       real_t v;
       asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(v) : "v"(row), "n"((N - 1) * 8) : "memory");
       PA[y * N + N - 1] = v;
-#endif
     }
   }
 #endif
@@ -210,12 +200,8 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 #define STFEM_GEN_WAVES 1
 #endif
 
-// dst rows are written once and not read again by this kernel
-#ifdef STFEM_NT_STORES
-#define STFEM_DST_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
+// (non-temporal dst stores were measured in round 1: no effect)
 #define STFEM_DST_STORE(ptr, val) (*(ptr) = (val))
-#endif
 
 template <int P, int NBM, int MINW, bool ADD, bool COEF, bool GEN, int COLOR>
 __global__ __launch_bounds__(tile_threads(P, NBM), tile_min_blocks(P, NBM, MINW))
@@ -400,13 +386,6 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     }
 
     STFEM_TL(1);
-#ifdef STFEM_EARLY_PREFETCH // experiment: the next layer's gather is issued before the core, into a second buffer
-    real_t PB[SX][N * N];
-    if (!last_layer && !(ex & 1)) {
-      STFEM_UNROLL
-      for (int h = 0; h < SX; ++h) load_plane_async<P, ASYNC_LOADS>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PB[h]);
-    }
-#endif
     STFEM_UNROLL
     for (int h = 0; h < SX; ++h) {
       real_t aK[NBM], aM[NBM];
@@ -500,22 +479,10 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     }
     // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
     // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
-#ifdef STFEM_EARLY_PREFETCH
-    if (!last_layer && !(ex & 1)) {
-      wait_vmcnt_imm<0>();
-      STFEM_UNROLL
-      for (int h = 0; h < SX; ++h) {
-        pin(PB[h]);
-        STFEM_UNROLL
-        for (int e = 0; e < N * N; ++e) PA[h][e] = PB[h][e];
-      }
-    }
-#else
     if (!last_layer && !(ex & 1)) {
       STFEM_UNROLL
       for (int h = 0; h < SX; ++h) load_plane_async<P, ASYNC_LOADS>(src_lane[h] + plane_stride * (int64_t(P) * (cz + 1)), prm.nx, PA[h]);
     }
-#endif
     STFEM_TL(6);
     STFEM_LAYER_BARRIER();
     STFEM_TL(7);
@@ -674,7 +641,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
       int n_o = 0;
       STFEM_UNROLL
       for (int o = 0; o < (TY + RPP - 1) / RPP; ++o) n_o += (RPI * wave_u + RPP * o < ymax) ? 1 : 0;
-#if !defined(STFEM_F32) && !defined(STFEM_EARLY_PREFETCH)
+#if !defined(STFEM_F32)
       if (ASYNC_LOADS) wait_vmcnt((ADD || (ex & 8) || (ex & 64)) ? 0 : prm.nbo * kend * n_o);
 #else
       (void)n_o;
@@ -833,17 +800,9 @@ template <int P, int NBM, int WV> int tile_occupancy_w(bool general)
 template <int P, int NBM> int tile_occupancy_t(bool general)
 {
 #ifdef STFEM_F32
-#ifdef STFEM_F32_WAVES
-  return tile_occupancy_w<P, NBM, STFEM_F32_WAVES>(general);
-#else
   return tile_occupancy_w<P, NBM, 4>(general);
-#endif
 #else
-#ifdef STFEM_ALLOW_W3 // experiment builds only: the 168-VGPR variants spill for some (P, NBM), see load_plane_async
-  return tile_wg_per_cu(P, NBM) == 3 ? tile_occupancy_w<P, NBM, 3>(general) : tile_occupancy_w<P, NBM, 2>(general);
-#else
-  return tile_occupancy_w<P, NBM, 2>(general);
-#endif
+  return tile_occupancy_w<P, NBM, 2>(general); // (the 168-VGPR, three-per-CU variants spill for some (P, NBM))
 #endif
 }
 
@@ -851,17 +810,9 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
 {
 #ifdef STFEM_F32
   // half the registers and half the LDS per workgroup: twice the waves per SIMD
-#ifdef STFEM_F32_WAVES
-  return launch_tile_w<P, NBM, STFEM_F32_WAVES>(prm, tp, st);
-#else
   return launch_tile_w<P, NBM, 4>(prm, tp, st);
-#endif
-#else
-#ifdef STFEM_ALLOW_W3
-  return tile_wg_per_cu(P, NBM) == 3 ? launch_tile_w<P, NBM, 3>(prm, tp, st) : launch_tile_w<P, NBM, 2>(prm, tp, st);
 #else
   return launch_tile_w<P, NBM, 2>(prm, tp, st);
-#endif
 #endif
 }
 
