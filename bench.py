@@ -60,20 +60,21 @@ def cpu_baseline(stfem, degree, r, cells, threads):
                       f"across cells and OpenMP on {threads} cores; deal.II is unavailable, so not the reference binary"}
 
 
-def measured_traffic(kernel_name):
+def measured_traffic(kernel_name, general):
     """HBM bytes per vmult from the committed rocprofv3 PMC passes of THIS command
-    (profiles/latest/traffic.json, written by tools/profile.sh): WRITE_SIZE + 2 x FETCH_SIZE,
-    the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md.  None if the
-    profile does not belong to the kernel variant that ran."""
-    path = os.path.join(ROOT, "profiles", "latest", "traffic.json")
+    (profiles/latest/traffic.json for the Cartesian cfg-1 run, traffic_general.json for the perturbed
+    72^3 mesh; written by tools/profile.sh): WRITE_SIZE + 2 x FETCH_SIZE, the factor 2 being the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md.  None if the profile does not belong to the kernel
+    variant that ran."""
+    path = os.path.join(ROOT, "profiles", "latest", "traffic_general.json" if general else "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         if not kernel_name.startswith(t.get("kernel", "?")) or "f32" in kernel_name:
-            return None
-        return 1024.0 * (2.0 * t["fetch_kb_per_vmult"] + t["write_kb_per_vmult"])
+            return None, None
+        return 1024.0 * (2.0 * t["fetch_kb_per_vmult"] + t["write_kb_per_vmult"]), os.path.relpath(path, ROOT)
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def main():
@@ -287,8 +288,9 @@ def main():
         # 16 B per space-time DoF per vmult (8 B src read + 8 B dst write)
         alg_bytes = 2.0 * esz * nb * ndofs  # fp64: 16 B per DoF; fp32: 8 B
         achieved = alg_bytes / (kms * 1e-3) / 1e9
-        traffic = (measured_traffic(ctx.last_kernel_name)
-                   if (world, n, p, r, args.distort, args.number) == (1, 72, 4, 2, 0.0, "double") else None)
+        traffic, traffic_file = (measured_traffic(ctx.last_kernel_name, bool(args.distort))
+                                 if (world, n, p, r, args.number) == (1, 72, 4, 2, "double") and args.distort in (0.0, 0.15)
+                                 else (None, None))
         out = {
             "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s",
             "value": total_dofs * args.steps / elapsed,
@@ -309,7 +311,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_source": ("profiles/latest/traffic.json: rocprofv3 --pmc passes of this command "
+                         "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes of this command "
                                             "(FETCH_SIZE x 2 + WRITE_SIZE), committed, not measured in this run")
                          if traffic is not None else None,
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},

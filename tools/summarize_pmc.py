@@ -32,7 +32,7 @@ try:
         acc = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            if "stfem" in k:
+            if "stfem" in k and ("st_sweep" in k or "fixup" in k):  # the kernels of a vmult, not the set-up ones
                 acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
         for k, cs in acc.items():
             for c, v in cs.items():
