@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the N > 1 path on ONE GPU (all ranks share cuda:0, the interface planes "
                          "are staged through host memory); timings of such a run mean nothing")
+    ap.add_argument("--exchange", choices=["abi", "torch"], default=None,
+                    help="N > 1: who moves the interface planes: abi = RCCL behind the C-ABI (stfem_halo_begin/end, "
+                         "default with --backend nccl), torch = torch.distributed P2P around stfem_plane_pack/unpack "
+                         "(default with --backend gloo; also taken if the RCCL communicator cannot be created)")
     ap.add_argument("--check", action="store_true",
                     help="N > 1: compare every rank's slab of the sharded vmult with a single-domain vmult of the "
                          "whole mesh computed on the same GPU (small meshes only)")
@@ -215,6 +219,23 @@ def main():
             return []
 
     xdist = dist if args.backend == "nccl" else StagedDist()
+    if args.exchange is None:
+        args.exchange = "abi" if args.backend == "nccl" else "torch"
+    comm = None
+    if world > 1 and args.exchange == "abi":
+        def bcast(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        try:
+            comm = dmod.Communicator(rank, world, local_rank, bcast)
+        except Exception as e:  # noqa: BLE001  (reported below; every rank must take the same path)
+            print(f"[bench] rank {rank}: RCCL communicator behind the C-ABI not available ({e})", file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if comm is not None else 0], device=xdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm, args.exchange = None, "torch"
+    lo_rank, up_rank = dmod.neighbours(slab)
 
     kernel_ms, exchange_ms = [], []
 
@@ -227,7 +248,11 @@ def main():
             e1.record()
             kernel_ms.append((e0, e1))
         if world > 1:
-            dmod.sharded_vmult(slab, lambda: None, pack, unpack_add, bufs, xdist)
+            if comm is not None:
+                comm.halo_begin(ctx, dst, lo_rank, up_rank, stream())
+                comm.halo_end(ctx, dst, stream())
+            else:
+                dmod.sharded_vmult(slab, lambda: None, pack, unpack_add, bufs, xdist)
             if record:  # pack + RCCL send/recv + unpack-add of the interface planes
                 e2 = torch.cuda.Event(enable_timing=True)
                 e2.record()
@@ -307,7 +332,10 @@ def main():
                        "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name,
                        # rank 0, per step: the local cell sweep and the packed interface-plane exchange
                        # (weak scaling loses exactly the second; no other communication on the path)
-                       "local_sweep_ms": kms, "exchange_ms": xms},
+                       "local_sweep_ms": kms, "exchange_ms": xms,
+                       "exchange": None if world == 1 else
+                       ("RCCL behind the C-ABI (stfem_halo_begin/end)" if comm is not None
+                        else f"torch.distributed ({args.backend}) P2P around stfem_plane_pack/unpack")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
@@ -320,6 +348,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(stfem, p, r, args.cpu_cells or args.cells,
                                                max(1, min(16, len(os.sched_getaffinity(0)))))  # a 1-GPU box grants 16 cores
         print(json.dumps(out))
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -79,6 +79,17 @@ SIGNATURES = {
     "stfem_st_diagonal": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _vp, _vp]),
     "stfem_plane_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "stfem_plane_unpack": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "stfem_n_dofs_1d": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "stfem_comm_get_unique_id": (C.c_int, [_vp]),
+    "stfem_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "stfem_comm_destroy": (None, [_vp]),
+    "stfem_comm_rank": (C.c_int, [_vp]),
+    "stfem_comm_size": (C.c_int, [_vp]),
+    "stfem_comm_last_error": (C.c_char_p, []),
+    "stfem_ghost_update": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "stfem_halo_begin": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "stfem_halo_end": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "stfem_dot_global": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _dp, _vp]),
     "stfem_fe_time_weights": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
     "stfem_fe_time_weights_wave": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int,
                                              _dp, _dp, _dp, _dp, _dp]),

@@ -146,6 +146,7 @@ const char *stfem_strerror(int s)
     case STFEM_ERR_SHAPE_MISMATCH: return "block count or size mismatch";
     case STFEM_ERR_ALIAS: return "dst aliases src";
     case STFEM_ERR_OUT_OF_MEMORY: return "out of memory";
+    case STFEM_ERR_COMM: return "RCCL error";
     default: return "unknown status";
   }
 }
@@ -263,6 +264,12 @@ void stfem_ctx_destroy(stfem_ctx *c)
 
 int64_t stfem_n_dofs(const stfem_ctx *c) { return c ? c->ndofs : 0; }
 int64_t stfem_n_cells(const stfem_ctx *c) { return c ? c->ncells : 0; }
+int stfem_n_dofs_1d(const stfem_ctx *c, int32_t nd[3])
+{
+  if (!c || !nd) return STFEM_ERR_INVALID_ARGUMENT;
+  for (int d = 0; d < 3; ++d) nd[d] = c->nd[d];
+  return STFEM_OK;
+}
 int stfem_is_cartesian(const stfem_ctx *c) { return c && c->cartesian ? 1 : 0; }
 int stfem_ctx_precision(const stfem_ctx *c) { return c ? c->prec : -1; }
 const char *stfem_last_kernel_name(const stfem_ctx *c) { return c ? c->last_kernel : ""; }

@@ -102,3 +102,65 @@ def sharded_vmult(slab, local_vmult, pack_plane, unpack_add_plane, bufs, dist):
         unpack_add_plane(-1, bufs["tr"])
     if slab.has_lower:
         unpack_add_plane(0, bufs["br"])
+
+
+class Communicator:
+    """The RCCL communicator behind the C-ABI (include/stfem.h: stfem_comm_*): what a C++ caller uses
+    instead of torch.distributed.  `bcast(bytes_or_None) -> bytes` carries the 128-byte id from rank 0
+    to the others (MPI_Bcast on the deal.II side; torch.distributed / gloo in bench.py and the tests)."""
+
+    def __init__(self, rank, world, device, bcast):
+        import ctypes as C
+        from . import lib, _check
+        self._L = lib()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _check(self._L.stfem_comm_get_unique_id(uid), "stfem_comm_get_unique_id")
+        raw = bcast(uid.raw if rank == 0 else None)
+        assert len(raw) == 128
+        h = C.c_void_p()
+        rc = self._L.stfem_comm_create(C.create_string_buffer(raw, 128), rank, world, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"stfem_comm_create: status {rc}: {self._L.stfem_comm_last_error().decode()}")
+        self._h, self.rank, self.world = h, rank, world
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.stfem_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: status {rc}: {self._L.stfem_comm_last_error().decode()}")
+
+    def ghost_update(self, ctx, vec, lower, upper, stream=None):
+        self._chk(self._L.stfem_ghost_update(ctx._h, self._h, vec._h, lower, upper, stream), "stfem_ghost_update")
+
+    def halo_begin(self, ctx, vec, lower, upper, stream=None):
+        self._chk(self._L.stfem_halo_begin(ctx._h, self._h, vec._h, lower, upper, stream), "stfem_halo_begin")
+
+    def halo_end(self, ctx, vec, stream=None):
+        self._chk(self._L.stfem_halo_end(ctx._h, self._h, vec._h, stream), "stfem_halo_end")
+
+    def dot(self, ctx, a, b, n_own):
+        import ctypes as C
+        out = C.c_double(0.0)
+        self._chk(self._L.stfem_dot_global(ctx._h, self._h, a._h, b._h, n_own, C.byref(out), None), "stfem_dot_global")
+        return out.value
+
+
+def neighbours(slab):
+    """(lower_rank, upper_rank) of a z-slab, -1 at the ends of the mesh."""
+    return (slab.rank - 1 if slab.has_lower else -1, slab.rank + 1 if slab.has_upper else -1)
+
+
+def sharded_vmult_abi(slab, comm, ctx, local_vmult, dst, stream=None):
+    """sharded_vmult with the exchange inside the C-ABI (RCCL): sweep, then one packed exchange."""
+    local_vmult()
+    if slab.world == 1:
+        return
+    lo, up = neighbours(slab)
+    comm.halo_begin(ctx, dst, lo, up, stream)
+    comm.halo_end(ctx, dst, stream)

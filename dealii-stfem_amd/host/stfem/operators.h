@@ -12,6 +12,32 @@
 
 namespace stfem {
 
+// src.update_ghost_values() / dst.compress(add) of a partitioned context (no-ops otherwise)
+inline void ghost_update(const Context &c, stfem_vec *v, void *stream)
+{
+  if (c.partitioned())
+    Communicator::check_comm(stfem_ghost_update(c.h, c.comm->handle(), v, c.lower_rank, c.upper_rank, stream),
+                             "stfem_ghost_update");
+}
+inline void compress_add(const Context &c, stfem_vec *v, void *stream)
+{
+  if (!c.partitioned()) return;
+  Communicator::check_comm(stfem_halo_begin(c.h, c.comm->handle(), v, c.lower_rank, c.upper_rank, stream), "stfem_halo_begin");
+  Communicator::check_comm(stfem_halo_end(c.h, c.comm->handle(), v, stream), "stfem_halo_end");
+}
+// BlockVector::operator* (an MPI_Allreduce in the reference): owned entries only, summed over the ranks
+template <typename Number> double dot(const BlockVectorT<Number> &a, const BlockVectorT<Number> &b, void *stream = nullptr)
+{
+  const Context &c = *a.context();
+  double out = 0.0;
+  if (c.comm)
+    Communicator::check_comm(stfem_dot_global(c.h, c.comm->handle(), a.handle(), b.handle(), c.n_owned(), &out, stream),
+                             "stfem_dot_global");
+  else
+    check(stfem_dot(c.h, a.handle(), b.handle(), 0, &out, stream), "stfem_dot");
+  return out;
+}
+
 // Structured hexahedral mesh of one rank (GridGenerator::subdivided_hyper_rectangle +
 // refine_global [+ distort_random], tests/tp_01.cc:82-90) and zero Dirichlet boundary ids.
 struct Mesh {
@@ -51,10 +77,23 @@ public:
 
   template <typename Number2> void initialize_dof_vector(VectorT<Number2> &vec) const { vec.reinit(ctx_); }
 
+  // z-slab partition of the mesh (parallel::distributed::Triangulation in the reference, tests/tp_01.cc:80):
+  // this rank's mesh is one slab (Mesh::dirichlet_mask without the interface faces); every vmult then
+  // brackets its cell loop as MatrixFree::cell_loop does (operators.h:1016-1017): ghost update of src,
+  // sweep, one packed add-exchange of the interface planes of dst.  Shared by all operators on this context.
+  void set_partition(const std::shared_ptr<Communicator> &comm, int lower_rank, int upper_rank)
+  {
+    ctx_->comm = comm;
+    ctx_->lower_rank = lower_rank;
+    ctx_->upper_rank = upper_rank;
+  }
+
   void vmult(VectorType &dst, const VectorType &src, void *stream = nullptr) const
   {
+    ghost_update(*ctx_, src.handle(), stream);
     check(stfem_space_vmult(ctx_->h, mass_matrix_scaling, laplace_matrix_scaling, dst.handle(), src.handle(), stream),
           "MatrixFreeOperator::vmult");
+    compress_add(*ctx_, dst.handle(), stream);
   }
 
   // operators.h:1060-1087; one value per cell, or per (cell, quadrature point)
@@ -199,9 +238,26 @@ private:
       a[i] = double(Alpha.data()[i]);
       b[i] = double(Beta.data()[i]);
     }
-    check(stfem_st_vmult(K.context()->h, int(Alpha.m()), int(Alpha.n()), a.data(), b.data(), transpose, add,
+    const Context &c = *K.context();
+    ghost_update(c, src.handle(), stream);
+    if (add && c.partitioned()) { // the exchange adds the partials of THIS product only
+      BlockVectorType tmp;
+      tmp.reinit(K.context(), dst.n_blocks());
+      check(stfem_st_vmult(c.h, int(Alpha.m()), int(Alpha.n()), a.data(), b.data(), transpose, 0, tmp.handle(),
+                           src.handle(), stream),
+            "SystemMatrix::vmult");
+      compress_add(c, tmp.handle(), stream);
+      std::vector<double> eye(size_t(dst.n_blocks()) * dst.n_blocks(), 0.0);
+      for (unsigned i = 0; i < dst.n_blocks(); ++i) eye[size_t(i) * dst.n_blocks() + i] = 1.0;
+      check(stfem_tensorproduct_add(c.h, int(dst.n_blocks()), int(dst.n_blocks()), eye.data(), dst.handle(), tmp.handle(),
+                                    stream),
+            "SystemMatrix::vmult_slice_add");
+      return;
+    }
+    check(stfem_st_vmult(c.h, int(Alpha.m()), int(Alpha.n()), a.data(), b.data(), transpose, add,
                          dst.handle(), src.handle(), stream),
           "SystemMatrix::vmult");
+    compress_add(c, dst.handle(), stream);
   }
   const SystemMatrixTypeK &K;
   const SystemMatrixTypeM &M;

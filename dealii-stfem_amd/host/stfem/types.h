@@ -6,6 +6,7 @@
 #pragma once
 #include "../../../include/stfem.h"
 
+#include <array>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -52,13 +53,57 @@ private:
   std::vector<Number> v_;
 };
 
-// owning handle of an stfem_ctx, shared by the K and M operators of one mesh
+// The MPI side of LinearAlgebra::distributed::Vector for z-slab partitions: one RCCL communicator per
+// process (include/stfem.h: stfem_comm_*).  The 128-byte id comes from unique_id() on one rank and is
+// broadcast by the caller (MPI_Bcast in a deal.II program).
+class Communicator {
+public:
+  using UniqueId = std::array<char, STFEM_COMM_ID_BYTES>;
+  static UniqueId unique_id()
+  {
+    UniqueId id;
+    check_comm(stfem_comm_get_unique_id(id.data()), "stfem_comm_get_unique_id");
+    return id;
+  }
+  Communicator(const UniqueId &id, int rank, int world, int device)
+  {
+    check_comm(stfem_comm_create(id.data(), rank, world, device, &h_), "stfem_comm_create");
+  }
+  ~Communicator() { stfem_comm_destroy(h_); }
+  Communicator(const Communicator &) = delete;
+  Communicator &operator=(const Communicator &) = delete;
+  int rank() const { return stfem_comm_rank(h_); }
+  int size() const { return stfem_comm_size(h_); }
+  stfem_comm *handle() const { return h_; }
+  static void check_comm(int status, const char *what)
+  {
+    if (status == STFEM_ERR_COMM || status == STFEM_ERR_UNSUPPORTED)
+      throw Error(status, std::string(what) + ": " + stfem_comm_last_error());
+    check(status, what);
+  }
+
+private:
+  stfem_comm *h_ = nullptr;
+};
+
+// owning handle of an stfem_ctx, shared by the K and M operators of one mesh; on a partitioned mesh
+// also the communicator and the ranks holding the slabs below / above (-1: none)
 struct Context {
   stfem_ctx *h = nullptr;
+  std::shared_ptr<Communicator> comm;
+  int lower_rank = -1, upper_rank = -1;
   explicit Context(stfem_ctx *c) : h(c) {}
   ~Context() { stfem_ctx_destroy(h); }
   Context(const Context &) = delete;
   Context &operator=(const Context &) = delete;
+  bool partitioned() const { return comm && (lower_rank >= 0 || upper_rank >= 0); }
+  // entries of a block this rank owns: all but the top plane where a slab above owns it
+  int64_t n_owned() const
+  {
+    int32_t nd[3];
+    check(stfem_n_dofs_1d(h, nd), "stfem_n_dofs_1d");
+    return int64_t(nd[0]) * nd[1] * (upper_rank >= 0 ? nd[2] - 1 : nd[2]);
+  }
 };
 
 template <typename Number> class BlockVectorT;

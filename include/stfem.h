@@ -37,7 +37,8 @@ typedef enum {
   STFEM_ERR_NO_DEVICE = -4,
   STFEM_ERR_SHAPE_MISMATCH = -5,
   STFEM_ERR_ALIAS = -6, /* vmult(dst, src) with dst == src (reference forbids it too) */
-  STFEM_ERR_OUT_OF_MEMORY = -7
+  STFEM_ERR_OUT_OF_MEMORY = -7,
+  STFEM_ERR_COMM = -8 /* an RCCL call failed: see stfem_comm_last_error */
 } stfem_status;
 
 typedef struct stfem_ctx stfem_ctx; /* replaces MatrixFree + MatrixFreeOperator state */
@@ -73,6 +74,8 @@ void stfem_ctx_destroy(stfem_ctx *ctx);
 /* MatrixFreeOperator::m() (operators.h:1047-1051): spatial DoFs on this rank */
 int64_t stfem_n_dofs(const stfem_ctx *ctx);
 int64_t stfem_n_cells(const stfem_ctx *ctx);
+/* DoFs per direction of this rank's box, nd[d] = degree * ncell[d] + 1 (x fastest in every block) */
+int stfem_n_dofs_1d(const stfem_ctx *ctx, int32_t nd[3]);
 /* 1 if the mesh was recognised as an axis-aligned uniform box (Cartesian fast path) */
 int stfem_is_cartesian(const stfem_ctx *ctx);
 /* 0 = fp64, 1 = fp32: the Number type of the operator (MatrixFreeOperator<dim, n_components, Number>) */
@@ -151,6 +154,37 @@ int stfem_dot(stfem_ctx *ctx, const stfem_vec *a, const stfem_vec *b, int64_t n_
 int stfem_plane_pack(stfem_ctx *ctx, const stfem_vec *v, int iz, void *device_buf, void *stream);
 int stfem_plane_unpack(stfem_ctx *ctx, stfem_vec *v, int iz, const void *device_buf, int add,
                        void *stream);
+
+/* The exchange itself, over RCCL, for callers that do not bring their own transport: one process per
+ * GPU, ranks = z-slabs of the mesh.  Replaces the MPI side of LinearAlgebra::distributed::Vector
+ * (update_ghost_values / compress(add), operators.h:1016-1017) and of Vector::operator* (MPI_Allreduce).
+ * The 128-byte id is created on one rank and broadcast by the host code (MPI_Bcast on the deal.II side),
+ * then every rank creates its communicator (collective).  RCCL is bound at run time: without librccl.so
+ * stfem_comm_create returns STFEM_ERR_UNSUPPORTED.  lower_rank / upper_rank: the ranks owning the slab
+ * below / above, -1 at the ends of the mesh. */
+#define STFEM_COMM_ID_BYTES 128
+typedef struct stfem_comm stfem_comm;
+int stfem_comm_get_unique_id(void *id);
+int stfem_comm_create(const void *id, int rank, int world, int device, stfem_comm **out);
+void stfem_comm_destroy(stfem_comm *comm);
+int stfem_comm_rank(const stfem_comm *comm);
+int stfem_comm_size(const stfem_comm *comm);
+const char *stfem_comm_last_error(void);
+/* src.update_ghost_values(): the top plane of every block <- the upper neighbour's bottom plane.
+ * Enqueued on `stream` (the transfer itself runs on the communicator's own stream in between). */
+int stfem_ghost_update(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, int lower_rank, int upper_rank,
+                       void *stream);
+/* dst.compress(add) + update_ghost_values in one exchange: after the local cell sweep both copies of an
+ * interface plane hold partial sums; each side sends its partial to the other and adds what it receives,
+ * all temporal blocks in one message per neighbour.  begin: packs on `stream` and starts the transfers on
+ * the communicator's stream; work enqueued on `stream` between begin and end overlaps with them;
+ * end: `stream` waits for the arrival and adds.  One exchange in flight per communicator. */
+int stfem_halo_begin(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, int lower_rank, int upper_rank,
+                     void *stream);
+int stfem_halo_end(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, void *stream);
+/* stfem_dot followed by the sum over all ranks (synchronous) */
+int stfem_dot_global(stfem_ctx *ctx, stfem_comm *comm, const stfem_vec *a, const stfem_vec *b,
+                     int64_t n_own, double *out, void *stream);
 
 /* Host-side helpers mirroring include/fe_time.h (type: 0 = CGP, 1 = DG).  Row-major outputs,
  * nb = (type==0 ? r : r+1) * n_timesteps_at_once; returns nb or a negative status.

@@ -19,6 +19,7 @@ def test_host_mirror_compiles():
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(HOST, "test_host_mirror"))
     assert os.path.exists(os.path.join(HOST, "test_host_stokes"))
+    assert os.path.exists(os.path.join(HOST, "test_host_sharded"))
 
 
 @pytest.mark.gpu
