@@ -12,17 +12,17 @@
 //       wKp_j * (div u, q)                       into every pressure destination block j
 // with fp64 atomics (destinations zeroed first).  No CPU fallback.
 //
-// Thread layout: one wave owns two cells (32 lanes each, 27 = 3^3 active): in the evaluation
-// phase a lane is a quadrature point, in the integration phase a velocity node (lanes 0..7 also
-// a pressure node).  The 89 cell DoFs and the 13 flux values per point go through LDS.  The FE_Q(2)
-// / FE_Q(1) shape values are products of 1D tables held in SGPRs (kernel arguments); the MappingQ1
+// Thread layout: one wave owns two cells (32 lanes each, 27 = 3^3 active).  Evaluation and
+// integration are sum-factorised (three 1D stages each, see stokes_cell_kernel); the MappingQ1
 // Jacobian is evaluated on the fly from the eight cell vertices (24 doubles per cell instead of a
-// stored metric).  This is a first, correct version: it is not sum-factorised and not tuned.
+// stored metric), or is a constant diagonal on axis-aligned boxes.  The scatter still uses fp64
+// atomics into zeroed destinations.
 #include "../../include/stfem.h"
 #include "host_tables.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -47,6 +47,8 @@ struct StokesParams {
   double wKu[MAXOUT], wKp[MAXOUT], wM[MAXOUT];
   double Su[9], Du[9], Sp[6]; // [q*3+a], [q*3+a], [q*2+a]
   double xq[3], wq[3];
+  int cart;                   // axis-aligned uniform cells: constant diagonal Jacobian
+  double hinv[3], detJ;       // 1 / h_d, hx hy hz
 };
 
 __device__ __forceinline__ bool constrained_u(const StokesParams &prm, int ix, int iy, int iz)
@@ -56,163 +58,228 @@ __device__ __forceinline__ bool constrained_u(const StokesParams &prm, int ix, i
          ((prm.dmask & 16) && iz == 0) || ((prm.dmask & 32) && iz == prm.ndu[2] - 1);
 }
 
-// 256 threads = 4 waves = 8 cells
+// Orders the LDS traffic of one wave (a cell lives in one half of a wave: no workgroup barrier needed)
+__device__ __forceinline__ void wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 256 threads = 4 waves = 8 cells at a time; the workgroups walk over the cells.
+// Sum-factorised: evaluation and integration are three 1D stages each (x, y, z), handed from lane to
+// lane through two wave-private LDS regions per cell that alternate as source and destination.
+//   evaluate : lane (a, b, c) = (q_x, n_y, n_z) -> (q_x, q_y, n_z) -> quadrature point (q_x, q_y, q_z)
+//   integrate: lane (q_x, q_y, n_z) -> (q_x, n_y, n_z) -> velocity node (n_x, n_y, n_z); the eight
+//              lanes with a, b, c < 2 also carry the pressure node (a, b, c)
+// The lane's rows / columns of the 1D tables stay in registers for the whole kernel.
+// CART: axis-aligned uniform cells (the context was created without vertices): constant diagonal Jacobian.
+template <bool CART>
 __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm)
 {
-  constexpr int CELL_LDS = 81 + 8 + 27 * 13; // u[3][27], p[8], per point: Fref[9], dq, mu[3]
-  __shared__ double smem[8 * CELL_LDS];
+  constexpr int RX = 351, RY = 351; // doubles per cell of the two regions (largest stage: 13 x 27)
+  __shared__ double smem[8 * (RX + RY)];
   __shared__ double tS[9], tD[9], tP[6]; // 1D tables [q*3+a], [q*3+a], [q*2+a]
   if (threadIdx.x < 9) { tS[threadIdx.x] = prm.Su[threadIdx.x]; tD[threadIdx.x] = prm.Du[threadIdx.x]; }
   if (threadIdx.x < 6) tP[threadIdx.x] = prm.Sp[threadIdx.x];
-  const int slot = threadIdx.x >> 5, t = threadIdx.x & 31;
-  const long long ncells = (long long)prm.ncx * prm.ncy * prm.ncz;
-  const long long cell = (long long)blockIdx.x * 8 + slot;
-  const bool cell_ok = cell < ncells;
-  const long long cc = cell_ok ? cell : 0;
-  const int cx = int(cc % prm.ncx), cy = int((cc / prm.ncx) % prm.ncy), cz = int(cc / ((long long)prm.ncx * prm.ncy));
-  double *ul = smem + slot * CELL_LDS, *pl = ul + 81, *fl = pl + 8;
-  const bool active = cell_ok && t < 27;
-  const int a = t % 3, b = (t / 3) % 3, c = t / 9; // node or quadrature point (x fastest)
-
-  // ---- gather (read_dof_values: constrained velocity entries read as 0)
-  const int ix = 2 * cx + a, iy = 2 * cy + b, iz = 2 * cz + c;
-  const bool con = constrained_u(prm, ix, iy, iz);
-  const long long gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
-  if (active) {
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp) ul[comp * 27 + t] = con ? 0.0 : prm.u[comp * prm.Nu + gu];
-  }
-  const int pa = t & 1, pb = (t >> 1) & 1, pc = (t >> 2) & 1;
-  const long long gp = (cx + pa) + (long long)prm.ndp[0] * ((cy + pb) + (long long)prm.ndp[1] * (cz + pc));
-  if (cell_ok && t < 8) pl[t] = prm.p ? prm.p[gp] : 0.0;
   __syncthreads();
+  const int slot = threadIdx.x >> 5, t32 = threadIdx.x & 31;
+  const bool lane27 = t32 < 27;
+  const int t = lane27 ? t32 : 0;
+  const int a = t % 3, b = (t / 3) % 3, c = t / 9;
+  const int a1 = a < 2 ? a : 1, b1 = b < 2 ? b : 1, c1 = c < 2 ? c : 1; // (pressure stages: clamped, unused where >= 2)
+  double *X = smem + slot * (RX + RY), *Y = X + RX;
+  // evaluation: row of this lane's quadrature index; integration: column of this lane's node index
+  double Sa[3], Da[3], Sb[3], Db[3], Sc[3], Dc[3], SaT[3], DaT[3], SbT[3], DbT[3], ScT[3], DcT[3];
+  double Pa[2], Pb[2], Pc[2], PaT[3], PbT[3], PcT[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    Sa[n] = tS[a * 3 + n]; Da[n] = tD[a * 3 + n]; Sb[n] = tS[b * 3 + n]; Db[n] = tD[b * 3 + n];
+    Sc[n] = tS[c * 3 + n]; Dc[n] = tD[c * 3 + n];
+    SaT[n] = tS[n * 3 + a]; DaT[n] = tD[n * 3 + a]; SbT[n] = tS[n * 3 + b]; DbT[n] = tD[n * 3 + b];
+    ScT[n] = tS[n * 3 + c]; DcT[n] = tD[n * 3 + c];
+    PaT[n] = tP[n * 2 + a1]; PbT[n] = tP[n * 2 + b1]; PcT[n] = tP[n * 2 + c1];
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) { Pa[n] = tP[a * 2 + n]; Pb[n] = tP[b * 2 + n]; Pc[n] = tP[c * 2 + n]; }
+  const double wabc = prm.wq[a] * prm.wq[b] * prm.wq[c];
+  const bool pnode = lane27 && a < 2 && b < 2 && c < 2; // this lane also integrates pressure node (a, b, c)
+  const long long ncells = (long long)prm.ncx * prm.ncy * prm.ncz;
 
-  // ---- evaluate + quadrature-point operation (this lane = point (a, b, c))
-  double Ji[3][3], JxW = 0.0;
-  if (active) {
-    const double x = prm.xq[a], y = prm.xq[b], z = prm.xq[c];
-    const double fx[2] = {1 - x, x}, fy[2] = {1 - y, y}, fz[2] = {1 - z, z}, dd[2] = {-1.0, 1.0};
-    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    const long long nvx = prm.ncx + 1, nvy = prm.ncy + 1;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const double *X = prm.vertices + 3 * ((cx + i) + nvx * ((cy + j) + nvy * (long long)(cz + k)));
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const double Xd = X[d];
-            J[d][0] += Xd * dd[i] * fy[j] * fz[k];
-            J[d][1] += Xd * fx[i] * dd[j] * fz[k];
-            J[d][2] += Xd * fx[i] * fy[j] * dd[k];
-          }
-        }
-    const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
-                       J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-    const double id = 1.0 / det;
-    Ji[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id;
-    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
-    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
-    Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * id;
-    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
-    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
-    Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id;
-    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
-    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
-    JxW = det * prm.wq[a] * prm.wq[b] * prm.wq[c];
+  // every half-wave walks through its own contiguous run of cells: cells sharing nodes are handled one
+  // after the other by the same lanes instead of at the same time by neighbouring ones (their atomics
+  // on the shared nodes would serialise in L2)
+  const long long nhalf = (long long)gridDim.x * 8, run = (ncells + nhalf - 1) / nhalf;
+  const long long first = ((long long)blockIdx.x * 8 + slot) * run;
+  for (long long it = 0; it < run; ++it) {
+    const long long cell = first + it;
+    const bool cell_ok = cell < ncells;
+    const long long cc = cell_ok ? cell : 0;
+    const int cx = int(cc % prm.ncx), cy = int((cc / prm.ncx) % prm.ncy), cz = int(cc / ((long long)prm.ncx * prm.ncy));
+    const bool active = cell_ok && lane27;
 
-    // the node loops stay rolled (small code, few registers); 1D table rows come from LDS
-    double sx[3], dx[3];
+    // ---- gather (read_dof_values: constrained velocity entries read as 0): X = u[3][27], p[8]
+    const int ix = 2 * cx + a, iy = 2 * cy + b, iz = 2 * cz + c;
+    const bool con = constrained_u(prm, ix, iy, iz);
+    const long long gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
+    const long long gp = (cx + a1) + (long long)prm.ndp[0] * ((cy + b1) + (long long)prm.ndp[1] * (cz + c1));
+    if (active) {
 #pragma unroll
-    for (int n = 0; n < 3; ++n) { sx[n] = tS[a * 3 + n]; dx[n] = tD[a * 3 + n]; }
-    double gref[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, uval[3] = {0, 0, 0};
-#pragma unroll 1
-    for (int nc = 0; nc < 3; ++nc) {
-      const double sz = tS[c * 3 + nc], dz = tD[c * 3 + nc];
-#pragma unroll 1
-      for (int nb = 0; nb < 3; ++nb) {
-        const double sy = tS[b * 3 + nb], dy = tD[b * 3 + nb];
-        const double syz = sy * sz, dyz = dy * sz, sdz = sy * dz;
-#pragma unroll
-        for (int na = 0; na < 3; ++na) {
-          const int n = na + 3 * (nb + 3 * nc);
-          const double gx = dx[na] * syz, gy = sx[na] * dyz, gz = sx[na] * sdz, val = sx[na] * syz;
-#pragma unroll
-          for (int comp = 0; comp < 3; ++comp) {
-            const double w = ul[comp * 27 + n];
-            gref[comp][0] = fma(w, gx, gref[comp][0]);
-            gref[comp][1] = fma(w, gy, gref[comp][1]);
-            gref[comp][2] = fma(w, gz, gref[comp][2]);
-            uval[comp] = fma(w, val, uval[comp]);
-          }
-        }
-      }
+      for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = con ? 0.0 : prm.u[comp * prm.Nu + gu];
     }
-    double pval = 0.0;
-#pragma unroll
-    for (int nc = 0; nc < 2; ++nc)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int na = 0; na < 2; ++na)
-          pval = fma(pl[na + 2 * (nb + 2 * nc)], tP[a * 2 + na] * tP[b * 2 + nb] * tP[c * 2 + nc], pval);
-    double grad[3][3];
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp)
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        grad[comp][d] = gref[comp][0] * Ji[0][d] + gref[comp][1] * Ji[1][d] + gref[comp][2] * Ji[2][d];
-    const double divu = grad[0][0] + grad[1][1] + grad[2][2];
-    // operators.h:1547-1553, 1570 (weights applied at scatter time)
+    if (cell_ok && pnode) X[81 + a + 2 * b + 4 * c] = prm.p ? prm.p[gp] : 0.0;
+    wave_fence();
+
+    // ---- evaluate, x: (n_x, n_y, n_z) -> (q_x, n_y, n_z): values and x derivatives -> Y
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
-      double F[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) F[d] = (prm.nu * grad[comp][d] - (comp == d ? pval : 0.0)) * JxW;
-#pragma unroll
-      for (int e = 0; e < 3; ++e) fl[t * 13 + comp * 3 + e] = Ji[e][0] * F[0] + Ji[e][1] * F[1] + Ji[e][2] * F[2];
-      fl[t * 13 + 10 + comp] = uval[comp] * JxW;
+      const double *u = X + comp * 27 + 3 * b + 9 * c;
+      const double u0 = u[0], u1 = u[1], u2 = u[2];
+      Y[(comp * 2) * 27 + t] = fma(Sa[2], u2, fma(Sa[1], u1, Sa[0] * u0));
+      Y[(comp * 2 + 1) * 27 + t] = fma(Da[2], u2, fma(Da[1], u1, Da[0] * u0));
     }
-    fl[t * 13 + 9] = divu * JxW;
-  }
-  __syncthreads();
+    Y[162 + t] = fma(Pa[1], X[81 + 1 + 2 * b1 + 4 * c1], Pa[0] * X[81 + 2 * b1 + 4 * c1]); // pressure (n_y, n_z < 2)
+    wave_fence();
+    // ---- y: -> (q_x, q_y, n_z): value, d/dx, d/dy -> X
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+      const double *v = Y + (comp * 2) * 27 + a + 9 * c, *d = v + 27;
+      const double v0 = v[0], v1 = v[3], v2 = v[6], d0 = d[0], d1 = d[3], d2 = d[6];
+      X[(comp * 3) * 27 + t] = fma(Sb[2], v2, fma(Sb[1], v1, Sb[0] * v0));
+      X[(comp * 3 + 1) * 27 + t] = fma(Sb[2], d2, fma(Sb[1], d1, Sb[0] * d0));
+      X[(comp * 3 + 2) * 27 + t] = fma(Db[2], v2, fma(Db[1], v1, Db[0] * v0));
+    }
+    X[243 + t] = fma(Pb[1], Y[162 + a + 3 + 9 * c1], Pb[0] * Y[162 + a + 9 * c1]);
+    wave_fence();
+    // ---- z: -> quadrature point (a, b, c): value and reference gradient in registers
+    double uval[3], gref[3][3];
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+      const double *v = X + (comp * 3) * 27 + a + 3 * b, *dx = v + 27, *dy = v + 54;
+      const double v0 = v[0], v1 = v[9], v2 = v[18];
+      uval[comp] = fma(Sc[2], v2, fma(Sc[1], v1, Sc[0] * v0));
+      gref[comp][0] = fma(Sc[2], dx[18], fma(Sc[1], dx[9], Sc[0] * dx[0]));
+      gref[comp][1] = fma(Sc[2], dy[18], fma(Sc[1], dy[9], Sc[0] * dy[0]));
+      gref[comp][2] = fma(Dc[2], v2, fma(Dc[1], v1, Dc[0] * v0));
+    }
+    const double pval = fma(Pc[1], X[243 + a + 3 * b + 9], Pc[0] * X[243 + a + 3 * b]);
 
-  // ---- integrate (this lane = velocity node (a, b, c); lanes 0..7 also pressure node)
-  double rK[3] = {0, 0, 0}, rM[3] = {0, 0, 0}, rP = 0.0;
-  if (active) {
-#pragma unroll 1
-    for (int qc = 0; qc < 3; ++qc) {
-      const double szv = tS[qc * 3 + c], dzv = tD[qc * 3 + c], pz = tP[qc * 2 + pc];
-#pragma unroll 1
-      for (int qb = 0; qb < 3; ++qb) {
-        const double syv = tS[qb * 3 + b], dyv = tD[qb * 3 + b], py = tP[qb * 2 + pb];
-        const double syz = syv * szv, dyz = dyv * szv, sdz = syv * dzv;
+    // ---- quadrature-point operation (operators.h:1547-1553, 1570; weights applied at scatter time) -> Y
+    if (CART) {
+      const double JxW = prm.detJ * wabc;
 #pragma unroll
-        for (int qa = 0; qa < 3; ++qa) {
-          const int q = qa + 3 * (qb + 3 * qc);
-          const double sxv = tS[qa * 3 + a], dxv = tD[qa * 3 + a];
-          const double gx = dxv * syz, gy = sxv * dyz, gz = sxv * sdz, val = sxv * syz;
-          const double *f = fl + q * 13;
+      for (int comp = 0; comp < 3; ++comp) {
 #pragma unroll
-          for (int comp = 0; comp < 3; ++comp) {
-            rK[comp] = fma(gx, f[comp * 3], fma(gy, f[comp * 3 + 1], fma(gz, f[comp * 3 + 2], rK[comp])));
-            rM[comp] = fma(val, f[10 + comp], rM[comp]);
-          }
-          if (t < 8) rP = fma(tP[qa * 2 + pa] * py * pz, f[9], rP);
+        for (int e = 0; e < 3; ++e) {
+          const double g = gref[comp][e] * prm.hinv[e];
+          Y[(comp * 3 + e) * 27 + t] = (prm.nu * g - (comp == e ? pval : 0.0)) * JxW * prm.hinv[e];
         }
+        Y[(10 + comp) * 27 + t] = uval[comp] * JxW;
       }
-    }
-    // ---- distribute_local_to_global (constrained velocity rows are not written)
-    for (int j = 0; j < prm.nout; ++j) {
-      if (!con && prm.out_u[j]) {
+      Y[9 * 27 + t] = (gref[0][0] * prm.hinv[0] + gref[1][1] * prm.hinv[1] + gref[2][2] * prm.hinv[2]) * JxW;
+    } else {
+      const double x = prm.xq[a], y = prm.xq[b], z = prm.xq[c];
+      const double fx[2] = {1 - x, x}, fy[2] = {1 - y, y}, fz[2] = {1 - z, z}, dd[2] = {-1.0, 1.0};
+      double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      const long long nvx = prm.ncx + 1, nvy = prm.ncy + 1;
 #pragma unroll
-        for (int comp = 0; comp < 3; ++comp)
-          atomicAdd(prm.out_u[j] + comp * prm.Nu + gu, prm.wKu[j] * rK[comp] + prm.wM[j] * rM[comp]);
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const double *V = prm.vertices + 3 * ((cx + i) + nvx * ((cy + j) + nvy * (long long)(cz + k)));
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const double Vd = V[d];
+              J[d][0] += Vd * dd[i] * fy[j] * fz[k];
+              J[d][1] += Vd * fx[i] * dd[j] * fz[k];
+              J[d][2] += Vd * fx[i] * fy[j] * dd[k];
+            }
+          }
+      const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                         J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      const double id = 1.0 / det;
+      double Ji[3][3];
+      Ji[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id;
+      Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+      Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+      Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * id;
+      Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+      Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+      Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id;
+      Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+      Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+      const double JxW = det * wabc;
+      double divu = 0.0;
+#pragma unroll
+      for (int comp = 0; comp < 3; ++comp) {
+        double F[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double g = gref[comp][0] * Ji[0][d] + gref[comp][1] * Ji[1][d] + gref[comp][2] * Ji[2][d];
+          if (comp == d) divu += g;
+          F[d] = (prm.nu * g - (comp == d ? pval : 0.0)) * JxW;
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) Y[(comp * 3 + e) * 27 + t] = Ji[e][0] * F[0] + Ji[e][1] * F[1] + Ji[e][2] * F[2];
+        Y[(10 + comp) * 27 + t] = uval[comp] * JxW;
       }
-      if (t < 8 && prm.out_p[j]) atomicAdd(prm.out_p[j] + gp, prm.wKp[j] * rP);
+      Y[9 * 27 + t] = divu * JxW;
     }
+    wave_fence();
+
+    // ---- integrate, z: quadrature point -> (q_x, q_y, n_z) -> X
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+      const double *f0 = Y + (comp * 3) * 27 + a + 3 * b, *f1 = f0 + 27, *f2 = f0 + 54, *fm = Y + (10 + comp) * 27 + a + 3 * b;
+      X[(comp * 4) * 27 + t] = fma(ScT[2], f0[18], fma(ScT[1], f0[9], ScT[0] * f0[0]));
+      X[(comp * 4 + 1) * 27 + t] = fma(ScT[2], f1[18], fma(ScT[1], f1[9], ScT[0] * f1[0]));
+      X[(comp * 4 + 2) * 27 + t] = fma(DcT[2], f2[18], fma(DcT[1], f2[9], DcT[0] * f2[0]));
+      X[(comp * 4 + 3) * 27 + t] = fma(ScT[2], fm[18], fma(ScT[1], fm[9], ScT[0] * fm[0]));
+    }
+    {
+      const double *fd = Y + 9 * 27 + a + 3 * b;
+      X[324 + t] = fma(PcT[2], fd[18], fma(PcT[1], fd[9], PcT[0] * fd[0]));
+    }
+    wave_fence();
+    // ---- y: -> (q_x, n_y, n_z) -> Y
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+      const double *g0 = X + (comp * 4) * 27 + a + 9 * c, *g1 = g0 + 27, *g2 = g0 + 54, *gm = g0 + 81;
+      Y[(comp * 3) * 27 + t] = fma(SbT[2], g0[6], fma(SbT[1], g0[3], SbT[0] * g0[0]));
+      Y[(comp * 3 + 1) * 27 + t] = fma(DbT[2], g1[6], fma(DbT[1], g1[3], DbT[0] * g1[0])) +
+                                   fma(SbT[2], g2[6], fma(SbT[1], g2[3], SbT[0] * g2[0]));
+      Y[(comp * 3 + 2) * 27 + t] = fma(SbT[2], gm[6], fma(SbT[1], gm[3], SbT[0] * gm[0]));
+    }
+    {
+      const double *gd = X + 324 + a + 9 * c;
+      Y[243 + t] = fma(PbT[2], gd[6], fma(PbT[1], gd[3], PbT[0] * gd[0]));
+    }
+    wave_fence();
+    // ---- x: -> node (a, b, c)
+    double rK[3], rM[3];
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+      const double *h0 = Y + (comp * 3) * 27 + 3 * b + 9 * c, *h1 = h0 + 27, *hm = h0 + 54;
+      rK[comp] = fma(DaT[2], h0[2], fma(DaT[1], h0[1], DaT[0] * h0[0])) + fma(SaT[2], h1[2], fma(SaT[1], h1[1], SaT[0] * h1[0]));
+      rM[comp] = fma(SaT[2], hm[2], fma(SaT[1], hm[1], SaT[0] * hm[0]));
+    }
+    const double *hd = Y + 243 + 3 * b + 9 * c;
+    const double rP = fma(PaT[2], hd[2], fma(PaT[1], hd[1], PaT[0] * hd[0]));
+
+    // ---- distribute_local_to_global (constrained velocity rows are not written)
+    if (active) {
+      for (int j = 0; j < prm.nout; ++j) {
+        if (!con && prm.out_u[j]) {
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp)
+            atomicAdd(prm.out_u[j] + comp * prm.Nu + gu, prm.wKu[j] * rK[comp] + prm.wM[j] * rM[comp]);
+        }
+        if (pnode && prm.out_p[j]) atomicAdd(prm.out_p[j] + gp, prm.wKp[j] * rP);
+      }
+    }
+    wave_fence(); // the next cell's gather overwrites X
   }
 }
 
@@ -226,6 +293,7 @@ struct stfem_stokes_ctx {
   int dmask = 0;
   double nu = 1.0;
   double *d_vertices = nullptr;
+  int n_cu = 256;
   StokesParams base;
 };
 
@@ -263,6 +331,10 @@ int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double
   stfem_stokes_ctx *c = new (std::nothrow) stfem_stokes_ctx;
   if (!c) return STFEM_ERR_OUT_OF_MEMORY;
   c->device = mesh->device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, mesh->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  }
   c->dmask = mesh->dirichlet_mask;
   c->nu = viscosity;
   for (int d = 0; d < 3; ++d) {
@@ -312,6 +384,13 @@ int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double
   b.Nu = c->Nu; b.Np = c->Np;
   b.dmask = c->dmask;
   b.nu = c->nu;
+  b.cart = mesh->vertices ? 0 : 1;
+  b.detJ = 1.0;
+  for (int d = 0; d < 3; ++d) {
+    const double h = (mesh->upper[d] - mesh->lower[d]) / c->nc[d];
+    b.hinv[d] = 1.0 / h;
+    b.detJ *= h;
+  }
   *out = c;
   return STFEM_OK;
 }
@@ -371,7 +450,10 @@ static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
 {
   const long long ncells = (long long)c->nc[0] * c->nc[1] * c->nc[2];
   (void)hipGetLastError();
-  hipLaunchKernelGGL(stokes_cell_kernel, dim3((unsigned)((ncells + 7) / 8)), dim3(256), 0, st, prm);
+  // the workgroups walk over the cells: a few per CU keep every SIMD busy
+  const unsigned grid = (unsigned)std::min<long long>((ncells + 7) / 8, (long long)c->n_cu * 8);
+  if (prm.cart) hipLaunchKernelGGL(stokes_cell_kernel<true>, dim3(grid), dim3(256), 0, st, prm);
+  else hipLaunchKernelGGL(stokes_cell_kernel<false>, dim3(grid), dim3(256), 0, st, prm);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_stokes_err, sizeof(g_stokes_err), "stokes_cell_kernel: %s", hipGetErrorString(e));
