@@ -111,23 +111,52 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   // on the shared nodes would serialise in L2)
   const long long nhalf = (long long)gridDim.x * 8, run = (ncells + nhalf - 1) / nhalf;
   const long long first = ((long long)blockIdx.x * 8 + slot) * run;
-  for (long long it = 0; it < run; ++it) {
-    const long long cell = first + it;
-    const bool cell_ok = cell < ncells;
-    const long long cc = cell_ok ? cell : 0;
-    const int cx = int(cc % prm.ncx), cy = int((cc / prm.ncx) % prm.ncy), cz = int(cc / ((long long)prm.ncx * prm.ncy));
-    const bool active = cell_ok && lane27;
-
-    // ---- gather (read_dof_values: constrained velocity entries read as 0): X = u[3][27], p[8]
-    const int ix = 2 * cx + a, iy = 2 * cy + b, iz = 2 * cz + c;
-    const bool con = constrained_u(prm, ix, iy, iz);
-    const long long gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
-    const long long gp = (cx + a1) + (long long)prm.ndp[0] * ((cy + b1) + (long long)prm.ndp[1] * (cz + c1));
-    if (active) {
+  // the DoFs of a cell are fetched while the previous cell is being computed
+  struct CellIds {
+    int cx, cy, cz;
+    bool ok, con;
+    long long gu, gp;
+  };
+  auto ids = [&](long long cell) {
+    CellIds q;
+    q.ok = cell < ncells && cell < first + run;
+    const long long cc = q.ok ? cell : 0;
+    q.cx = int(cc % prm.ncx); q.cy = int((cc / prm.ncx) % prm.ncy); q.cz = int(cc / ((long long)prm.ncx * prm.ncy));
+    const int ix = 2 * q.cx + a, iy = 2 * q.cy + b, iz = 2 * q.cz + c;
+    q.con = constrained_u(prm, ix, iy, iz);
+    q.gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
+    q.gp = (q.cx + a1) + (long long)prm.ndp[0] * ((q.cy + b1) + (long long)prm.ndp[1] * (q.cz + c1));
+    return q;
+  };
+  double un[3] = {0, 0, 0}, pn = 0.0;
+  auto fetch = [&](const CellIds &q) { // read_dof_values: constrained velocity entries read as 0
+    if (q.ok && lane27 && !q.con) {
 #pragma unroll
-      for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = con ? 0.0 : prm.u[comp * prm.Nu + gu];
+      for (int comp = 0; comp < 3; ++comp) un[comp] = prm.u[comp * prm.Nu + q.gu];
+    } else {
+      un[0] = un[1] = un[2] = 0.0;
     }
-    if (cell_ok && pnode) X[81 + a + 2 * b + 4 * c] = prm.p ? prm.p[gp] : 0.0;
+    pn = (q.ok && pnode && prm.p) ? prm.p[q.gp] : 0.0;
+  };
+  CellIds nxt = ids(first);
+  fetch(nxt);
+  for (long long it = 0; it < run; ++it) {
+    const CellIds cur = nxt;
+    const bool cell_ok = cur.ok;
+    const int cx = cur.cx, cy = cur.cy, cz = cur.cz;
+    const bool con = cur.con;
+    const long long gu = cur.gu, gp = cur.gp;
+    const bool active = cell_ok && lane27;
+    (void)cx; (void)cy; (void)cz;
+
+    // ---- gather: X = u[3][27], p[8]
+    if (lane27) {
+#pragma unroll
+      for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = un[comp];
+    }
+    if (pnode) X[81 + a + 2 * b + 4 * c] = pn;
+    nxt = ids(first + it + 1);
+    fetch(nxt);
     wave_fence();
 
     // ---- evaluate, x: (n_x, n_y, n_z) -> (q_x, n_y, n_z): values and x derivatives -> Y
