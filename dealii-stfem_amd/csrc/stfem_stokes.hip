@@ -10,7 +10,8 @@
 // Here ONE launch per source time dof evaluates the cell once and scatters
 //       wKu_j * (nu K u - B^T p) + wM_j * M u   into every velocity destination block j,
 //       wKp_j * (div u, q)                       into every pressure destination block j
-// with fp64 atomics (destinations zeroed first).  No CPU fallback.
+// in eight launches, one per cell colour (cells of one colour share no DoF), with plain loads and
+// stores: no atomics, no zeroing, bitwise reproducible.  No CPU fallback.
 //
 // Thread layout: one wave owns two cells (32 lanes each, 27 = 3^3 active).  Evaluation and
 // integration are sum-factorised (three 1D stages each, see stokes_cell_kernel); the MappingQ1
@@ -25,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -47,6 +49,8 @@ struct StokesParams {
   double wKu[MAXOUT], wKp[MAXOUT], wM[MAXOUT];
   double Su[9], Du[9], Sp[6]; // [q*3+a], [q*3+a], [q*2+a]
   double xq[3], wq[3];
+  int colour;                 // this launch handles the cells with (cx & 1) + 2 (cy & 1) + 4 (cz & 1) == colour
+  int store_u[MAXOUT], store_p[MAXOUT]; // 1: the first cell to touch a DoF (lowest colour) stores, the others add; 0: all add
   int cart;                   // axis-aligned uniform cells: constant diagonal Jacobian
   double hinv[3], detJ;       // 1 / h_d, hx hy hz
 };
@@ -104,7 +108,11 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   for (int n = 0; n < 2; ++n) { Pa[n] = tP[a * 2 + n]; Pb[n] = tP[b * 2 + n]; Pc[n] = tP[c * 2 + n]; }
   const double wabc = prm.wq[a] * prm.wq[b] * prm.wq[c];
   const bool pnode = lane27 && a < 2 && b < 2 && c < 2; // this lane also integrates pressure node (a, b, c)
-  const long long ncells = (long long)prm.ncx * prm.ncy * prm.ncz;
+  // the cells of one colour share no DoF: the eight colours run as eight launches, lowest first, and
+  // scatter with plain loads and stores (no atomics, no zeroing of the destinations, deterministic)
+  const int px = prm.colour & 1, py = (prm.colour >> 1) & 1, pz = prm.colour >> 2;
+  const int ncxc = (prm.ncx - px + 1) / 2, ncyc = (prm.ncy - py + 1) / 2, nczc = (prm.ncz - pz + 1) / 2;
+  const long long ncells = (long long)ncxc * ncyc * nczc;
 
   // every half-wave walks through its own contiguous run of cells: cells sharing nodes are handled one
   // after the other by the same lanes instead of at the same time by neighbouring ones (their atomics
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     CellIds q;
     q.ok = cell < ncells && cell < first + run;
     const long long cc = q.ok ? cell : 0;
-    q.cx = int(cc % prm.ncx); q.cy = int((cc / prm.ncx) % prm.ncy); q.cz = int(cc / ((long long)prm.ncx * prm.ncy));
+    q.cx = 2 * int(cc % ncxc) + px; q.cy = 2 * int((cc / ncxc) % ncyc) + py; q.cz = 2 * int(cc / ((long long)ncxc * ncyc)) + pz;
     const int ix = 2 * q.cx + a, iy = 2 * q.cy + b, iz = 2 * q.cz + c;
     q.con = constrained_u(prm, ix, iy, iz);
     q.gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
@@ -297,15 +305,35 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     const double *hd = Y + 243 + 3 * b + 9 * c;
     const double rP = fma(PaT[2], hd[2], fma(PaT[1], hd[1], PaT[0] * hd[0]));
 
-    // ---- distribute_local_to_global (constrained velocity rows are not written)
+    // ---- distribute_local_to_global: constrained velocity rows stay 0.  A DoF on a face shared with a
+    // neighbouring cell is first touched by the cell whose colour bits are 0 in all shared directions.
     if (active) {
+      const bool fu = !((a == 0 && cx > 0 && px) || (a == 2 && cx < prm.ncx - 1 && px) ||
+                        (b == 0 && cy > 0 && py) || (b == 2 && cy < prm.ncy - 1 && py) ||
+                        (c == 0 && cz > 0 && pz) || (c == 2 && cz < prm.ncz - 1 && pz));
+      const bool fp = !((a == 0 && cx > 0 && px) || (a == 1 && cx < prm.ncx - 1 && px) ||
+                        (b == 0 && cy > 0 && py) || (b == 1 && cy < prm.ncy - 1 && py) ||
+                        (c == 0 && cz > 0 && pz) || (c == 1 && cz < prm.ncz - 1 && pz));
       for (int j = 0; j < prm.nout; ++j) {
-        if (!con && prm.out_u[j]) {
+        if (prm.out_u[j]) {
+          double *d = prm.out_u[j] + gu;
+          if (prm.store_u[j] && fu) {
 #pragma unroll
-          for (int comp = 0; comp < 3; ++comp)
-            atomicAdd(prm.out_u[j] + comp * prm.Nu + gu, prm.wKu[j] * rK[comp] + prm.wM[j] * rM[comp]);
+            for (int comp = 0; comp < 3; ++comp)
+              d[comp * prm.Nu] = con ? 0.0 : prm.wKu[j] * rK[comp] + prm.wM[j] * rM[comp];
+          } else if (!con) {
+            double v[3];
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) v[comp] = d[comp * prm.Nu];
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) d[comp * prm.Nu] = v[comp] + (prm.wKu[j] * rK[comp] + prm.wM[j] * rM[comp]);
+          }
         }
-        if (pnode && prm.out_p[j]) atomicAdd(prm.out_p[j] + gp, prm.wKp[j] * rP);
+        if (pnode && prm.out_p[j]) {
+          double *d = prm.out_p[j] + gp;
+          if (prm.store_p[j] && fp) *d = prm.wKp[j] * rP;
+          else *d += prm.wKp[j] * rP;
+        }
       }
     }
     wave_fence(); // the next cell's gather overwrites X
@@ -477,12 +505,18 @@ int stfem_stokes_vector_download(stfem_stokes_ctx *c, int variable, const double
 
 static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
 {
-  const long long ncells = (long long)c->nc[0] * c->nc[1] * c->nc[2];
   (void)hipGetLastError();
-  // the workgroups walk over the cells: a few per CU keep every SIMD busy
-  const unsigned grid = (unsigned)std::min<long long>((ncells + 7) / 8, (long long)c->n_cu * 8);
-  if (prm.cart) hipLaunchKernelGGL(stokes_cell_kernel<true>, dim3(grid), dim3(256), 0, st, prm);
-  else hipLaunchKernelGGL(stokes_cell_kernel<false>, dim3(grid), dim3(256), 0, st, prm);
+  for (int colour = 0; colour < 8; ++colour) { // ascending: see store_u / store_p
+    const long long n = (long long)((c->nc[0] - (colour & 1) + 1) / 2) * ((c->nc[1] - ((colour >> 1) & 1) + 1) / 2) *
+                        ((c->nc[2] - (colour >> 2) + 1) / 2);
+    if (n == 0) continue;
+    prm.colour = colour;
+    // the workgroups walk over the cells; four times as many as are resident at once (two per CU) measured best:
+    // 1.00 against 1.35 ms for the cG(2) system on 64^3 cells, no difference for cG(1)
+    const unsigned grid = (unsigned)std::min<long long>((n + 7) / 8, (long long)c->n_cu * 8);
+    if (prm.cart) hipLaunchKernelGGL(stokes_cell_kernel<true>, dim3(grid), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(stokes_cell_kernel<false>, dim3(grid), dim3(256), 0, st, prm);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_stokes_err, sizeof(g_stokes_err), "stokes_cell_kernel: %s", hipGetErrorString(e));
@@ -498,12 +532,11 @@ int stfem_stokes_vmult(stfem_stokes_ctx *c, double *dst_u, double *dst_p, const 
   if (dst_u == src_u || dst_p == src_p) return STFEM_ERR_ALIAS;
   STOKES_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  STOKES_TRY(hipMemsetAsync(dst_u, 0, sizeof(double) * 3 * c->Nu, st));
-  STOKES_TRY(hipMemsetAsync(dst_p, 0, sizeof(double) * c->Np, st));
   StokesParams prm = c->base;
   prm.u = src_u; prm.p = src_p;
   prm.nout = 1;
   prm.out_u[0] = dst_u; prm.out_p[0] = dst_p;
+  prm.store_u[0] = prm.store_p[0] = 1; // dst is overwritten
   prm.wKu[0] = 1.0; prm.wKp[0] = 1.0; prm.wM[0] = 0.0;
   return stokes_launch(c, prm, st);
 }
@@ -514,11 +547,11 @@ int stfem_stokes_mass_vmult(stfem_stokes_ctx *c, double *dst_u, const double *sr
   if (dst_u == src_u) return STFEM_ERR_ALIAS;
   STOKES_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  STOKES_TRY(hipMemsetAsync(dst_u, 0, sizeof(double) * 3 * c->Nu, st));
   StokesParams prm = c->base;
   prm.u = src_u; prm.p = nullptr;
   prm.nout = 1;
   prm.out_u[0] = dst_u; prm.out_p[0] = nullptr;
+  prm.store_u[0] = 1;
   prm.wKu[0] = 0.0; prm.wKp[0] = 0.0; prm.wM[0] = 1.0;
   return stokes_launch(c, prm, st);
 }
@@ -540,11 +573,9 @@ int stfem_stokes_st_vmult(stfem_stokes_ctx *c, int n_timesteps_at_once, int n_ti
   }
   STOKES_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int it = 0; it < ns; ++it) // dst = 0.0 (operators.h:833)
-    for (int d = 0; d < nt; ++d) {
-      STOKES_TRY(hipMemsetAsync(dst_blocks[index(it, 0, d)], 0, sizeof(double) * 3 * c->Nu, st));
-      STOKES_TRY(hipMemsetAsync(dst_blocks[index(it, 1, d)], 0, sizeof(double) * c->Np, st));
-    }
+  // dst = 0.0 (operators.h:833): the first launch that reaches a block overwrites it; blocks no launch
+  // reaches are zeroed at the end
+  std::vector<char> written(nb, 0);
   const double eps10 = 10 * std::numeric_limits<double>::epsilon(); // internal::scatter, operators.h:106
   for (int it = 0; it < ns; ++it)
     for (int id = 0; id < nt; ++id) {
@@ -568,6 +599,10 @@ int stfem_stokes_st_vmult(stfem_stokes_ctx *c, int n_timesteps_at_once, int n_ti
           const int o = prm.nout++;
           prm.out_u[o] = (useU || useM) ? dst_blocks[ju] : nullptr;
           prm.out_p[o] = useP ? dst_blocks[jp] : nullptr;
+          prm.store_u[o] = prm.out_u[o] && !written[ju];
+          prm.store_p[o] = prm.out_p[o] && !written[jp];
+          if (prm.out_u[o]) written[ju] = 1;
+          if (prm.out_p[o]) written[jp] = 1;
           prm.wKu[o] = useU ? aU : 0.0;
           prm.wKp[o] = useP ? aP : 0.0;
           prm.wM[o] = useM ? bU : 0.0;
@@ -578,6 +613,11 @@ int stfem_stokes_st_vmult(stfem_stokes_ctx *c, int n_timesteps_at_once, int n_ti
         }
       const int rc = flush();
       if (rc != STFEM_OK) return rc;
+    }
+  for (int it = 0; it < ns; ++it)
+    for (int d = 0; d < nt; ++d) {
+      if (!written[index(it, 0, d)]) STOKES_TRY(hipMemsetAsync(dst_blocks[index(it, 0, d)], 0, sizeof(double) * 3 * c->Nu, st));
+      if (!written[index(it, 1, d)]) STOKES_TRY(hipMemsetAsync(dst_blocks[index(it, 1, d)], 0, sizeof(double) * c->Np, st));
     }
   return STFEM_OK;
 }
