@@ -65,6 +65,7 @@ SIGNATURES = {
     "stfem_set_coefficient": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "stfem_vector_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "stfem_vector_wrap": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "stfem_vector_rebind": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "stfem_vector_destroy": (None, [_vp]),
     "stfem_vector_n_blocks": (C.c_int, [_vp]),
     "stfem_vector_block": (_vp, [_vp, C.c_int]),
@@ -216,6 +217,13 @@ class BlockVector:
         if getattr(self, "_h", None) and _lib is not None:
             _lib.stfem_vector_destroy(self._h)
             self._h = None
+
+    def rebind(self, device_ptrs):
+        """Points a view (made with device_ptrs=...) at other device arrays without reallocating."""
+        arr = (_vp * len(device_ptrs))(*device_ptrs)
+        _check(lib().stfem_vector_rebind(self._h, len(device_ptrs), arr), "stfem_vector_rebind")
+        self.n_blocks = len(device_ptrs)
+        return self
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=np.float64)

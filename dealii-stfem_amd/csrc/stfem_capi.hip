@@ -344,6 +344,20 @@ int stfem_vector_wrap(stfem_ctx *c, int nb, void *const *blocks, stfem_vec **out
   return STFEM_OK;
 }
 
+int stfem_vector_rebind(stfem_vec *v, int nb, void *const *blocks)
+{
+  if (!v || v->owns || nb < 1 || !blocks) return STFEM_ERR_INVALID_ARGUMENT;
+  for (int b = 0; b < nb; ++b)
+    if (!blocks[b]) return STFEM_ERR_INVALID_ARGUMENT;
+  try {
+    v->blk.assign(blocks, blocks + nb); // no allocation while the block count does not grow
+  } catch (...) {
+    return STFEM_ERR_OUT_OF_MEMORY;
+  }
+  v->nb = nb;
+  return STFEM_OK;
+}
+
 void stfem_vector_destroy(stfem_vec *v)
 {
   if (!v) return;

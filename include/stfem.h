@@ -95,6 +95,9 @@ int stfem_vector_create(stfem_ctx *ctx, int n_blocks, stfem_vec **out);
  * LinearAlgebra::distributed::BlockVector<double, MemorySpace::Default>): one device pointer
  * per block, each stfem_n_dofs doubles.  Not freed by stfem_vector_destroy. */
 int stfem_vector_wrap(stfem_ctx *ctx, int n_blocks, void *const *device_blocks, stfem_vec **out);
+/* Point an existing view at other device arrays (the hot path of a binding keeps one view per argument
+ * and rebinds it per vmult: no allocation).  Only views made by stfem_vector_wrap can be rebound. */
+int stfem_vector_rebind(stfem_vec *v, int n_blocks, void *const *device_blocks);
 void stfem_vector_destroy(stfem_vec *v);
 int stfem_vector_n_blocks(const stfem_vec *v);
 void *stfem_vector_block(const stfem_vec *v, int block); /* device pointer */

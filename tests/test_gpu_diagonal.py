@@ -49,3 +49,29 @@ def test_space_time_diagonal_vs_fixture(name, golden_dir, oracle_mod):
     con = dK == 0
     if con.any():
         assert np.all(K.get_matrix_diagonal_inverse().download()[0][con] == 1.0)
+
+
+def test_vector_rebind():
+    """stfem_vector_rebind: one view re-pointed at other device arrays (what a binding does per vmult)."""
+    stfem = importlib.import_module("dealii-stfem_amd")
+    p, nc, nb = 2, (3, 2, 4), 2
+    ctx = stfem.MatrixFreeOperator(p, nc)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    rng = np.random.default_rng(5)
+    X1, X2 = rng.uniform(-1, 1, (2, nb, ctx.n_dofs))
+    v1, v2 = stfem.BlockVector(ctx, nb).upload(X1), stfem.BlockVector(ctx, nb).upload(X2)
+    d1, d2 = A.initialize_dof_vector(), A.initialize_dof_vector()
+    A.vmult(d1, v1)
+    A.vmult(d2, v2)
+    view = stfem.BlockVector(ctx, device_ptrs=[v1.block_ptr(b) for b in range(nb)])
+    out = A.initialize_dof_vector()
+    A.vmult(out, view)
+    assert np.array_equal(out.download(), d1.download())
+    view.rebind([v2.block_ptr(b) for b in range(nb)])
+    A.vmult(out, view)
+    assert np.array_equal(out.download(), d2.download())
+    with pytest.raises(stfem.StfemError):
+        v1.rebind([v2.block_ptr(b) for b in range(nb)])  # an owning vector cannot be re-pointed
+    with pytest.raises(stfem.StfemError):
+        view.rebind([None, v2.block_ptr(1)])
