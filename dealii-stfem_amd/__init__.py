@@ -91,6 +91,11 @@ SIGNATURES = {
     "stfem_halo_begin": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "stfem_halo_end": (C.c_int, [_vp, _vp, _vp, _vp]),
     "stfem_dot_global": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _dp, _vp]),
+    "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
+    "stfem_vanka_destroy": (None, [_vp]),
+    "stfem_vanka_n_classes": (C.c_int, [_vp]),
+    "stfem_vanka_vmult": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "stfem_vanka_last_error": (C.c_char_p, []),
     "stfem_fe_time_weights": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
     "stfem_fe_time_weights_wave": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int,
                                              _dp, _dp, _dp, _dp, _dp]),
@@ -324,6 +329,33 @@ class MatrixFreeOperator:
     @property
     def last_kernel_name(self):
         return lib().stfem_last_kernel_name(self._h).decode()
+
+
+class PreconditionVanka:
+    """stmg.h:619-907: cell-patch additive-Schwarz smoother of Alpha (x) K + Beta (x) M on one context."""
+
+    def __init__(self, ctx, Alpha, Beta):
+        self.ctx = ctx
+        A = np.ascontiguousarray(Alpha, dtype=np.float64)
+        B = np.ascontiguousarray(Beta, dtype=np.float64)
+        assert A.shape == B.shape and A.shape[0] == A.shape[1]
+        h = _vp()
+        _check(lib().stfem_vanka_create(ctx._h, A.shape[0], _p(A), _p(B), C.byref(h)), "stfem_vanka_create")
+        self._h, self.n_blocks = h, A.shape[0]
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.stfem_vanka_destroy(self._h)
+            self._h = None
+
+    @property
+    def n_classes(self):
+        return lib().stfem_vanka_n_classes(self._h)
+
+    def vmult(self, dst, src, stream=None):
+        _check(lib().stfem_vanka_vmult(self._h, dst._h, src._h, stream), "stfem_vanka_vmult")
+
+    smooth = vmult  # stmg.h:881-885
 
 
 class SystemMatrix:

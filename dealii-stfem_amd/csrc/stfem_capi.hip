@@ -2,6 +2,7 @@
 #include "../../include/stfem.h"
 
 #include "host_tables.h"
+#include "stfem_internal.h"
 #include "stfem_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -93,45 +94,6 @@ int hip_fail(hipError_t e, const char *what)
   } while (0)
 
 } // namespace
-
-struct stfem_ctx {
-  int p = 0, device = 0, n_cu = 0;
-  int nc[3] = {0, 0, 0}, nd[3] = {0, 0, 0};
-  int64_t ndofs = 0, ncells = 0;
-  int dmask = 0;
-  bool cartesian = false;
-  double lower[3] = {0, 0, 0}, h[3] = {1, 1, 1};
-  ShapeTables tab;
-  std::vector<double> vertices; // host copy (general meshes)
-  int prec = 0;                // 0 = fp64, 1 = fp32 (element type of vectors, coefficients, metric)
-  size_t es = sizeof(double);  // element size
-  void *d_coef[2] = {nullptr, nullptr}; // [0] mass, [1] laplace
-  int coef_layout[2] = {0, 0};
-  double *d_scratch = nullptr; // reductions (always double)
-  const char *last_kernel = "";
-  // tile variant: halo slabs (grown on demand)
-  void *d_halo = nullptr;
-  size_t halo_doubles = 0; // elements
-  int variant = 0; // 0 = pencil (default; tile where the pencil kernel has no instantiation), 1 = atomic, 2 = tile
-  // tuning / experiment switches, read once at context creation (STFEM_* environment variables)
-  int env_tile_lz = 0, env_exp = 0, env_stagger = 0, env_stagger_div = 256, env_pencil_ty = 0, env_pencil_lz = 0;
-  const char *env_timeline = nullptr;
-  int *d_work = nullptr;           // pencil variant: tile counters
-  long long *d_timeline = nullptr; // diagnostic builds: phase timestamps of the last apply
-  size_t tl_n = 0;
-  // general-geometry path: device copies of vertices and the 1D rule, metric terms per (cell, q)
-  double *d_vertices = nullptr, *d_rule = nullptr;
-  void *d_metric = nullptr;
-  bool metric_valid = false;
-  int metric_flags = -1; // which coefficients are baked into d_metric (bit0 laplace, bit1 mass)
-};
-
-struct stfem_vec {
-  stfem_ctx *ctx = nullptr;
-  int nb = 0;
-  bool owns = false;
-  std::vector<void *> blk; // device arrays of the context's element type
-};
 
 extern "C" {
 

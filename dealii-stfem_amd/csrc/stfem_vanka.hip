@@ -1,0 +1,417 @@
+// Cell-patch Vanka / additive-Schwarz smoother of the space-time system.
+//
+// Replaces PreconditionVanka (reference include/stmg.h:619-907) for the scalar system
+// A = Alpha (x) K + Beta (x) M on one rank:
+//   set-up (stmg.h:786-829, compute_block_matrix.h:50-139): per cell the block
+//       B_c(k + i n, l + j n) = valence(k) * (Beta(i,j) M(k,l) + Alpha(i,j) K(k,l)),   k, l = DoFs of the cell,
+//     K, M = the ASSEMBLED matrices with the zero-boundary constraints (tests/tp_01.cc:283-299), inverted by
+//     Gauss-Jordan;
+//   vmult (stmg.h:832-872): dst = sum over cells of scatter(B_c^-1 gather(src)).
+// On the axis-aligned uniform meshes this path serves (cfg 1), the restriction of an assembled Kronecker
+// matrix to a cell is the Kronecker product of restricted 1D matrices, and it only depends on which
+// neighbours the cell has: at most 27 different blocks per mesh instead of one 250 x 250 block per cell
+// (250 kB per Q4 x cG(2) cell in fp32).  The apply is then a GEMM per block class,
+//       Y[250 x cells] = B^-1[250 x 250] X[250 x cells],
+// with the gather and the scatter fused in: MFMA work (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32,
+// 125 kflop against 4 kB of DoF traffic per cell).  Cells are processed in eight colours (cells of one
+// colour share no DoF), so the scatter is plain load-add-store: no atomics, bitwise reproducible.
+// General meshes and non-constant coefficients need per-cell blocks: not built (STFEM_ERR_UNSUPPORTED).
+#include "stfem_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int VK_MAX_BLOCKS = 8;
+constexpr int KS = 8; // k rows of the inverse staged in LDS per step (two buffers: 32 KB for a 256-row block in fp64)
+
+struct VankaParams {
+  const void *src[VK_MAX_BLOCKS];
+  void *dst[VK_MAX_BLOCKS];
+  const void *blocks; // [class][kpad][mpad], element (row r, column k) of the inverse at [k][r]
+  const int *off;     // local node -> DoF offset from the cell's first node
+  const int *cell;    // [nquad * 64]: first DoF of the cell, -1 = padding
+  const int *cls;     // [nquad]
+  int nquad, m, mpad, kpad;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  // C/D of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  // C/D of v_mfma_f32_16x16x4_f32: column = lane & 15, row = 4 * (lane >> 4) + reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+// One workgroup = four waves = four batches of 16 cells of ONE block class; a wave holds the 16 x 16
+// accumulator tiles of all MT row tiles of its 16 cells.  The rows of the inverse pass through LDS in
+// slabs of KS, shared by the four waves.
+template <typename T, int NLOC, int MT>
+__global__ __launch_bounds__(256) void vanka_apply_kernel(const VankaParams prm)
+{
+  using M = Mfma<T>;
+  constexpr int MPAD = 16 * MT;
+  __shared__ T slab[2][KS * MPAD];
+  __shared__ int s_off[NLOC];
+  for (int i = threadIdx.x; i < NLOC; i += 256) s_off[i] = prm.off[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quad = blockIdx.x;
+  const T *Binv = static_cast<const T *>(prm.blocks) + size_t(prm.cls[quad]) * prm.kpad * MPAD;
+  const int base = prm.cell[(quad * 4 + wave) * 16 + (lane & 15)]; // this lane's cell (column of X and Y)
+  auto stage = [&](int s, int buf) { // rows [s KS, (s + 1) KS) of the (padded) inverse
+    const T *g = Binv + size_t(s) * KS * MPAD;
+    for (int i = threadIdx.x; i < KS * MPAD; i += 256) slab[buf][i] = g[i];
+  };
+  typename M::acc_t acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = typename M::acc_t{0, 0, 0, 0};
+  // this lane's row of X in k-step kk: krow = kk + (lane >> 4) -> (block, local node), advanced by 4 per step
+  int xblk = 0, xn = lane >> 4;
+  auto gather = [&]() -> T {
+    T v = T(0);
+    if (base >= 0 && xblk * NLOC + xn < prm.m) v = static_cast<const T *>(prm.src[xblk])[base + s_off[xn]];
+    xn += 4;
+    if (xn >= NLOC) { xn -= NLOC; ++xblk; }
+    return v;
+  };
+  const int nslab = prm.kpad / KS;
+  stage(0, 0);
+  __syncthreads();
+  T xnext = gather();
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) stage(s + 1, (s + 1) & 1);
+    const T *sl = slab[s & 1];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk += 4) {
+      const T x = xnext;
+      xnext = gather(); // (one step past the end reads nothing: xblk * NLOC + xn >= m)
+      const T *a = sl + (kk + (lane >> 4)) * MPAD + (lane & 15);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = M::mma(a[16 * t], x, acc[t]);
+    }
+    __syncthreads();
+  }
+  // scatter: rows of Y back to the DoFs of the cell (cells of one launch share none)
+  if (base >= 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + M::row(lane, r);
+        if (row < prm.m) {
+          const int blk = row / NLOC, n = row - blk * NLOC;
+          T *d = static_cast<T *>(prm.dst[blk]) + base + s_off[n];
+          *d += acc[t][r];
+        }
+      }
+  }
+}
+
+// in-place Gauss-Jordan inverse with partial pivoting (FullMatrix::gauss_jordan, stmg.h:828)
+bool invert(int n, std::vector<double> &A)
+{
+  std::vector<int> piv(n);
+  for (int c = 0; c < n; ++c) {
+    int p = c;
+    double best = std::abs(A[size_t(c) * n + c]);
+    for (int r = c + 1; r < n; ++r)
+      if (std::abs(A[size_t(r) * n + c]) > best) { best = std::abs(A[size_t(r) * n + c]); p = r; }
+    if (best == 0.0) return false;
+    piv[c] = p;
+    if (p != c)
+      for (int k = 0; k < n; ++k) std::swap(A[size_t(c) * n + k], A[size_t(p) * n + k]);
+    const double inv = 1.0 / A[size_t(c) * n + c];
+    A[size_t(c) * n + c] = 1.0;
+    for (int k = 0; k < n; ++k) A[size_t(c) * n + k] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = A[size_t(r) * n + c];
+      if (f == 0.0) continue;
+      A[size_t(r) * n + c] = 0.0;
+      for (int k = 0; k < n; ++k) A[size_t(r) * n + k] -= f * A[size_t(c) * n + k];
+    }
+  }
+  for (int c = n - 1; c >= 0; --c)
+    if (piv[c] != c)
+      for (int r = 0; r < n; ++r) std::swap(A[size_t(r) * n + c], A[size_t(r) * n + piv[c]]);
+  return true;
+}
+
+thread_local char g_vanka_err[256] = "";
+
+} // namespace
+
+struct stfem_vanka {
+  stfem_ctx *ctx = nullptr;
+  int nb = 0, nloc = 0, m = 0, mt = 0, mpad = 0, kpad = 0, nclasses = 0;
+  void *d_blocks = nullptr;
+  int *d_off = nullptr;
+  int *d_cell[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int *d_cls[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int nquad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+#define VK_TRY(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      snprintf(g_vanka_err, sizeof(g_vanka_err), "%s: %s", #call, hipGetErrorString(e_)); \
+      return STFEM_ERR_HIP;                                                           \
+    }                                                                                 \
+  } while (0)
+
+template <typename T, int NLOC> static int vanka_launch_mt(const stfem_vanka *v, const VankaParams &prm, int nquad, hipStream_t st)
+{
+  switch (v->mt) {
+#define VK_CASE(MT)                                                                                        \
+  case MT: hipLaunchKernelGGL((vanka_apply_kernel<T, NLOC, MT>), dim3(nquad), dim3(256), 0, st, prm); break;
+    VK_CASE(1) VK_CASE(2) VK_CASE(3) VK_CASE(4) VK_CASE(6) VK_CASE(8) VK_CASE(12) VK_CASE(16) VK_CASE(24)
+#undef VK_CASE
+    default: return STFEM_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+
+template <typename T> static int vanka_launch(const stfem_vanka *v, const VankaParams &prm, int nquad, hipStream_t st)
+{
+  switch (v->ctx->p) {
+    case 1: return vanka_launch_mt<T, 8>(v, prm, nquad, st);
+    case 2: return vanka_launch_mt<T, 27>(v, prm, nquad, st);
+    case 3: return vanka_launch_mt<T, 64>(v, prm, nquad, st);
+    case 4: return vanka_launch_mt<T, 125>(v, prm, nquad, st);
+    default: return STFEM_ERR_UNSUPPORTED;
+  }
+}
+
+// row tiles the kernel is instantiated for (16 rows each); the block is padded up to the next one
+static int round_tiles(int mt)
+{
+  const int avail[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+  for (int a : avail)
+    if (mt <= a) return a;
+  return 0;
+}
+
+extern "C" {
+
+const char *stfem_vanka_last_error(void) { return g_vanka_err; }
+
+int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *Beta, stfem_vanka **out)
+{
+  if (!c || !Alpha || !Beta || !out || nb < 1 || nb > VK_MAX_BLOCKS) return STFEM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  // one block per neighbour pattern needs identical cells: axis-aligned uniform mesh, no coefficient tables
+  if (!c->cartesian || c->coef_layout[0] != 0 || c->coef_layout[1] != 0) return STFEM_ERR_UNSUPPORTED;
+  const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
+  const int mt = round_tiles((m + 15) / 16);
+  if (mt == 0) return STFEM_ERR_UNSUPPORTED; // more than 384 rows per cell: Q4 with more than 3 temporal blocks
+  VK_TRY(hipSetDevice(c->device));
+  stfem_vanka *v = new (std::nothrow) stfem_vanka;
+  if (!v) return STFEM_ERR_OUT_OF_MEMORY;
+  v->ctx = c; v->nb = nb; v->nloc = nloc; v->m = m; v->mt = mt;
+  v->mpad = 16 * mt;
+  v->kpad = ((m + KS - 1) / KS) * KS;
+
+  // 1D nodal matrices of the reference cell: Mhat = S^T W S, Khat = D^T W D
+  const stfem::ShapeTables &tab = c->tab;
+  std::vector<double> Mh(n * n, 0.0), Kh(n * n, 0.0);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b)
+      for (int q = 0; q < n; ++q) {
+        Mh[a * n + b] += tab.wq[q] * tab.S[q * n + a] * tab.S[q * n + b];
+        Kh[a * n + b] += tab.wq[q] * tab.D[q * n + a] * tab.D[q * n + b];
+      }
+  // classes: per direction bit 0 = has a lower neighbour, bit 1 = has an upper neighbour
+  auto dir_class = [&](int d, int cd) { return (cd > 0 ? 1 : 0) | (cd < c->nc[d] - 1 ? 2 : 0); };
+  std::map<int, int> class_id;
+  std::vector<int> class_key;
+  for (int cz = 0; cz < c->nc[2]; ++cz)
+    for (int cy = 0; cy < c->nc[1]; ++cy)
+      for (int cx = 0; cx < c->nc[0]; ++cx) {
+        const int key = dir_class(0, cx) | (dir_class(1, cy) << 2) | (dir_class(2, cz) << 4);
+        if (!class_id.count(key)) {
+          class_id[key] = int(class_key.size());
+          class_key.push_back(key);
+        }
+      }
+  v->nclasses = int(class_key.size());
+  const size_t bsz = size_t(v->kpad) * v->mpad;
+  std::vector<double> all(bsz * v->nclasses, 0.0);
+  for (int ci = 0; ci < v->nclasses; ++ci) {
+    const int key = class_key[ci];
+    // restricted assembled 1D matrices: the end nodes also carry the neighbour's diagonal entry
+    std::vector<double> M1[3], K1[3];
+    bool con[3][8], shared[3][8];
+    for (int d = 0; d < 3; ++d) {
+      const int k = (key >> (2 * d)) & 3;
+      const double h = c->h[d];
+      M1[d].assign(n * n, 0.0);
+      K1[d].assign(n * n, 0.0);
+      for (int e = 0; e < n * n; ++e) {
+        M1[d][e] = h * Mh[e];
+        K1[d][e] = Kh[e] / h;
+      }
+      if (k & 1) { M1[d][0] += h * Mh[p * n + p]; K1[d][0] += Kh[p * n + p] / h; }
+      if (k & 2) { M1[d][p * n + p] += h * Mh[0]; K1[d][p * n + p] += Kh[0] / h; }
+      for (int a = 0; a < n; ++a) {
+        shared[d][a] = (a == 0 && (k & 1)) || (a == p && (k & 2));
+        con[d][a] = (a == 0 && !(k & 1) && (c->dmask & (1 << (2 * d)))) || (a == p && !(k & 2) && (c->dmask & (2 << (2 * d))));
+      }
+    }
+    std::vector<double> Kr(size_t(nloc) * nloc), Mr(size_t(nloc) * nloc), val(nloc);
+    std::vector<char> cn(nloc);
+    for (int kz = 0; kz < n; ++kz)
+      for (int jy = 0; jy < n; ++jy)
+        for (int ix = 0; ix < n; ++ix) {
+          const int r = ix + n * (jy + n * kz);
+          val[r] = (shared[0][ix] ? 2.0 : 1.0) * (shared[1][jy] ? 2.0 : 1.0) * (shared[2][kz] ? 2.0 : 1.0);
+          cn[r] = con[0][ix] || con[1][jy] || con[2][kz];
+          for (int kz2 = 0; kz2 < n; ++kz2)
+            for (int jy2 = 0; jy2 < n; ++jy2)
+              for (int ix2 = 0; ix2 < n; ++ix2) {
+                const int s = ix2 + n * (jy2 + n * kz2);
+                const double mx = M1[0][ix * n + ix2], my = M1[1][jy * n + jy2], mz = M1[2][kz * n + kz2];
+                const double kx = K1[0][ix * n + ix2], ky = K1[1][jy * n + jy2], kz1 = K1[2][kz * n + kz2];
+                Mr[size_t(r) * nloc + s] = mz * my * mx;
+                Kr[size_t(r) * nloc + s] = mz * my * kx + mz * ky * mx + kz1 * my * mx;
+              }
+        }
+    // zero-boundary constraints: row and column dropped, the diagonal of the unconstrained assembly stays
+    for (int r = 0; r < nloc; ++r)
+      if (cn[r])
+        for (int s = 0; s < nloc; ++s)
+          if (s != r) {
+            Kr[size_t(r) * nloc + s] = Kr[size_t(s) * nloc + r] = 0.0;
+            Mr[size_t(r) * nloc + s] = Mr[size_t(s) * nloc + r] = 0.0;
+          }
+    std::vector<double> B(size_t(m) * m);
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < nb; ++j)
+        for (int r = 0; r < nloc; ++r)
+          for (int s = 0; s < nloc; ++s)
+            B[size_t(i * nloc + r) * m + j * nloc + s] =
+              val[r] * (Beta[i * nb + j] * Mr[size_t(r) * nloc + s] + Alpha[i * nb + j] * Kr[size_t(r) * nloc + s]);
+    if (!invert(m, B)) {
+      snprintf(g_vanka_err, sizeof(g_vanka_err), "singular cell block (class %d)", key);
+      delete v;
+      return STFEM_ERR_INVALID_ARGUMENT;
+    }
+    double *dstb = all.data() + bsz * ci;
+    for (int r = 0; r < m; ++r)
+      for (int k = 0; k < m; ++k) dstb[size_t(k) * v->mpad + r] = B[size_t(r) * m + k];
+  }
+  // upload in the context's Number type
+  if (c->prec) {
+    std::vector<float> f(all.size());
+    for (size_t i = 0; i < all.size(); ++i) f[i] = float(all[i]);
+    if (hipMalloc(&v->d_blocks, f.size() * sizeof(float)) != hipSuccess) { delete v; return STFEM_ERR_OUT_OF_MEMORY; }
+    if (hipMemcpy(v->d_blocks, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { stfem_vanka_destroy(v); return STFEM_ERR_HIP; }
+  } else {
+    if (hipMalloc(&v->d_blocks, all.size() * sizeof(double)) != hipSuccess) { delete v; return STFEM_ERR_OUT_OF_MEMORY; }
+    if (hipMemcpy(v->d_blocks, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { stfem_vanka_destroy(v); return STFEM_ERR_HIP; }
+  }
+  std::vector<int> off(nloc);
+  for (int kz = 0; kz < n; ++kz)
+    for (int jy = 0; jy < n; ++jy)
+      for (int ix = 0; ix < n; ++ix) off[ix + n * (jy + n * kz)] = ix + c->nd[0] * (jy + c->nd[1] * kz);
+  if (hipMalloc(&v->d_off, nloc * sizeof(int)) != hipSuccess ||
+      hipMemcpy(v->d_off, off.data(), nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    stfem_vanka_destroy(v);
+    return STFEM_ERR_HIP;
+  }
+  // cell lists: per colour, grouped by class into batches of 16 cells, four batches of one class per workgroup
+  for (int colour = 0; colour < 8; ++colour) {
+    std::vector<std::vector<int>> by_class(v->nclasses);
+    for (int cz = colour >> 2; cz < c->nc[2]; cz += 2)
+      for (int cy = (colour >> 1) & 1; cy < c->nc[1]; cy += 2)
+        for (int cx = colour & 1; cx < c->nc[0]; cx += 2) {
+          const int key = dir_class(0, cx) | (dir_class(1, cy) << 2) | (dir_class(2, cz) << 4);
+          by_class[class_id[key]].push_back(p * cx + c->nd[0] * (p * cy + c->nd[1] * p * cz));
+        }
+    std::vector<int> cells, cls;
+    for (int ci = 0; ci < v->nclasses; ++ci) {
+      std::vector<int> &l = by_class[ci];
+      if (l.empty()) continue;
+      l.resize(((l.size() + 63) / 64) * 64, -1);
+      for (size_t q = 0; q < l.size() / 64; ++q) cls.push_back(ci);
+      cells.insert(cells.end(), l.begin(), l.end());
+    }
+    v->nquad[colour] = int(cls.size());
+    if (cls.empty()) continue;
+    if (hipMalloc(&v->d_cell[colour], cells.size() * sizeof(int)) != hipSuccess ||
+        hipMalloc(&v->d_cls[colour], cls.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(v->d_cell[colour], cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_cls[colour], cls.data(), cls.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      stfem_vanka_destroy(v);
+      return STFEM_ERR_HIP;
+    }
+  }
+  *out = v;
+  return STFEM_OK;
+}
+
+void stfem_vanka_destroy(stfem_vanka *v)
+{
+  if (!v) return;
+  (void)hipSetDevice(v->ctx->device);
+  if (v->d_blocks) (void)hipFree(v->d_blocks);
+  if (v->d_off) (void)hipFree(v->d_off);
+  for (int i = 0; i < 8; ++i) {
+    if (v->d_cell[i]) (void)hipFree(v->d_cell[i]);
+    if (v->d_cls[i]) (void)hipFree(v->d_cls[i]);
+  }
+  delete v;
+}
+
+int stfem_vanka_n_classes(const stfem_vanka *v) { return v ? v->nclasses : 0; }
+
+int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream)
+{
+  if (!v || !dst || !src) return STFEM_ERR_INVALID_ARGUMENT;
+  if (dst->ctx != v->ctx || src->ctx != v->ctx || dst->nb != v->nb || src->nb != v->nb) return STFEM_ERR_SHAPE_MISMATCH;
+  for (int i = 0; i < v->nb; ++i)
+    for (int j = 0; j < v->nb; ++j)
+      if (dst->blk[i] == src->blk[j]) return STFEM_ERR_ALIAS;
+  stfem_ctx *c = v->ctx;
+  VK_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int i = 0; i < v->nb; ++i) VK_TRY(hipMemsetAsync(dst->blk[i], 0, size_t(c->ndofs) * c->es, st)); // dst = 0 (stmg.h:836)
+  VankaParams prm;
+  std::memset(&prm, 0, sizeof(prm));
+  for (int i = 0; i < v->nb; ++i) {
+    prm.src[i] = src->blk[i];
+    prm.dst[i] = dst->blk[i];
+  }
+  prm.blocks = v->d_blocks;
+  prm.off = v->d_off;
+  prm.m = v->m; prm.mpad = v->mpad; prm.kpad = v->kpad;
+  (void)hipGetLastError();
+  for (int colour = 0; colour < 8; ++colour) {
+    if (v->nquad[colour] == 0) continue;
+    prm.cell = v->d_cell[colour];
+    prm.cls = v->d_cls[colour];
+    prm.nquad = v->nquad[colour];
+    const int rc = c->prec ? vanka_launch<float>(v, prm, prm.nquad, st) : vanka_launch<double>(v, prm, prm.nquad, st);
+    if (rc != STFEM_OK) {
+      snprintf(g_vanka_err, sizeof(g_vanka_err), "vanka_apply_kernel: %s", hipGetErrorString(hipGetLastError()));
+      return rc;
+    }
+  }
+  return STFEM_OK;
+}
+
+} // extern "C"

@@ -189,6 +189,20 @@ int stfem_halo_end(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, void *stream)
 int stfem_dot_global(stfem_ctx *ctx, stfem_comm *comm, const stfem_vec *a, const stfem_vec *b,
                      int64_t n_own, double *out, void *stream);
 
+/* Cell-patch Vanka / additive-Schwarz smoother of the space-time system A = Alpha (x) K + Beta (x) M:
+ * PreconditionVanka (include/stmg.h:619-907; set-up 786-829 with compute_block_matrix.h:50-139, apply
+ * 832-872).  create: builds and inverts the valence-weighted cell blocks of the ASSEMBLED matrices (zero
+ * boundary constraints as in tests/tp_01.cc:283-299); Alpha, Beta are n x n row-major.  This round: one
+ * rank, axis-aligned uniform meshes without coefficient tables (one block per neighbour pattern, at most 27);
+ * other contexts return STFEM_ERR_UNSUPPORTED.  vmult: dst = sum over cells of scatter(B_c^-1 gather(src)),
+ * dst is overwritten, dst must not alias src (as in the reference). */
+typedef struct stfem_vanka stfem_vanka;
+int stfem_vanka_create(stfem_ctx *ctx, int n, const double *alpha, const double *beta, stfem_vanka **out);
+void stfem_vanka_destroy(stfem_vanka *v);
+int stfem_vanka_n_classes(const stfem_vanka *v); /* distinct cell blocks held */
+int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream);
+const char *stfem_vanka_last_error(void);
+
 /* Host-side helpers mirroring include/fe_time.h (type: 0 = CGP, 1 = DG).  Row-major outputs,
  * nb = (type==0 ? r : r+1) * n_timesteps_at_once; returns nb or a negative status.
  * get_fe_time_weights (fe_time.h:351-409) */
