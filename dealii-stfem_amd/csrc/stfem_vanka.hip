@@ -61,47 +61,90 @@ template <> struct Mfma<float> {
 // accumulator tiles of all MT row tiles of its 16 cells.  The rows of the inverse pass through LDS in
 // slabs of KS, shared by the four waves.
 template <typename T, int NLOC, int MT>
-__global__ __launch_bounds__(256) void vanka_apply_kernel(const VankaParams prm)
+__global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams prm)
 {
   using M = Mfma<T>;
   constexpr int MPAD = 16 * MT;
+  constexpr int SR = (KS * MPAD + 255) / 256; // slab elements every thread moves
   __shared__ T slab[2][KS * MPAD];
-  __shared__ int s_off[NLOC];
-  for (int i = threadIdx.x; i < NLOC; i += 256) s_off[i] = prm.off[i];
+  // byte offset of row r = (block, local node) of X / Y from the first source / destination block, for the cell
+  // whose first DoF is 0; -1 beyond the last row.  (Indexing the kernel arguments with a lane's block number would
+  // make every gather a dependent pair of global loads.)
+  __shared__ long long s_src[MPAD], s_dst[MPAD];
+  for (int r = threadIdx.x; r < MPAD; r += 256) {
+    long long os = -1, od = -1;
+    if (r < prm.m) {
+      const int blk = r / NLOC, n = r - blk * NLOC;
+      const long long o = (long long)prm.off[n] * (long long)sizeof(T);
+#pragma unroll
+      for (int b = 0; b < VK_MAX_BLOCKS; ++b)
+        if (b == blk) {
+          os = (static_cast<const char *>(prm.src[b]) - static_cast<const char *>(prm.src[0])) + o;
+          od = (static_cast<char *>(prm.dst[b]) - static_cast<char *>(prm.dst[0])) + o;
+        }
+    }
+    s_src[r] = os;
+    s_dst[r] = od;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int quad = blockIdx.x;
   const T *Binv = static_cast<const T *>(prm.blocks) + size_t(prm.cls[quad]) * prm.kpad * MPAD;
   const int base = prm.cell[(quad * 4 + wave) * 16 + (lane & 15)]; // this lane's cell (column of X and Y)
-  auto stage = [&](int s, int buf) { // rows [s KS, (s + 1) KS) of the (padded) inverse
-    const T *g = Binv + size_t(s) * KS * MPAD;
-    for (int i = threadIdx.x; i < KS * MPAD; i += 256) slab[buf][i] = g[i];
+  const char *src0 = static_cast<const char *>(prm.src[0]) + (long long)(base < 0 ? 0 : base) * (long long)sizeof(T);
+  char *dst0 = static_cast<char *>(prm.dst[0]) + (long long)(base < 0 ? 0 : base) * (long long)sizeof(T);
+  // rows [s KS, (s + 1) KS) of the (padded) inverse: fetched into registers while the previous slab is
+  // multiplied, written to the other LDS buffer afterwards
+  T sreg[SR];
+  auto fetch = [&](int s) {
+    const T *g = Binv + size_t(s) * KS * MPAD + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < SR; ++q)
+      if (KS * MPAD % 256 == 0 || q * 256 + int(threadIdx.x) < KS * MPAD) sreg[q] = g[q * 256];
+  };
+  auto deposit = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < SR; ++q)
+      if (KS * MPAD % 256 == 0 || q * 256 + int(threadIdx.x) < KS * MPAD) slab[buf][q * 256 + threadIdx.x] = sreg[q];
   };
   typename M::acc_t acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = typename M::acc_t{0, 0, 0, 0};
-  // this lane's row of X in k-step kk: krow = kk + (lane >> 4) -> (block, local node), advanced by 4 per step
-  int xblk = 0, xn = lane >> 4;
+  // this lane's row of X in a k-step: krow = 4 step + (lane >> 4); the values are gathered one slab ahead
+  int krow = lane >> 4;
   auto gather = [&]() -> T {
     T v = T(0);
-    if (base >= 0 && xblk * NLOC + xn < prm.m) v = static_cast<const T *>(prm.src[xblk])[base + s_off[xn]];
-    xn += 4;
-    if (xn >= NLOC) { xn -= NLOC; ++xblk; }
+    if (krow < MPAD) {
+      const long long o = s_src[krow];
+      if (base >= 0 && o >= 0) v = *reinterpret_cast<const T *>(src0 + o);
+    }
+    krow += 4;
     return v;
   };
   const int nslab = prm.kpad / KS;
-  stage(0, 0);
+  fetch(0);
+  __syncthreads(); // the offset tables
+  T xcur[KS / 4], xnxt[KS / 4];
+#pragma unroll
+  for (int q = 0; q < KS / 4; ++q) xcur[q] = gather();
+  deposit(0);
   __syncthreads();
-  T xnext = gather();
   for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) stage(s + 1, (s + 1) & 1);
+    if (s + 1 < nslab) {
+      fetch(s + 1);
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) xnxt[q] = gather();
+    }
     const T *sl = slab[s & 1];
 #pragma unroll
-    for (int kk = 0; kk < KS; kk += 4) {
-      const T x = xnext;
-      xnext = gather(); // (one step past the end reads nothing: xblk * NLOC + xn >= m)
-      const T *a = sl + (kk + (lane >> 4)) * MPAD + (lane & 15);
+    for (int q = 0; q < KS / 4; ++q) {
+      const T *a = sl + (4 * q + (lane >> 4)) * MPAD + (lane & 15);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = M::mma(a[16 * t], x, acc[t]);
+      for (int t = 0; t < MT; ++t) acc[t] = M::mma(a[16 * t], xcur[q], acc[t]);
+    }
+    if (s + 1 < nslab) {
+      deposit((s + 1) & 1);
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) xcur[q] = xnxt[q];
     }
     __syncthreads();
   }
@@ -112,9 +155,9 @@ __global__ __launch_bounds__(256) void vanka_apply_kernel(const VankaParams prm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * t + M::row(lane, r);
-        if (row < prm.m) {
-          const int blk = row / NLOC, n = row - blk * NLOC;
-          T *d = static_cast<T *>(prm.dst[blk]) + base + s_off[n];
+        const long long o = s_dst[row];
+        if (o >= 0) {
+          T *d = reinterpret_cast<T *>(dst0 + o);
           *d += acc[t][r];
         }
       }
