@@ -94,6 +94,7 @@ SIGNATURES = {
     "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
     "stfem_vanka_destroy": (None, [_vp]),
     "stfem_vanka_n_classes": (C.c_int, [_vp]),
+    "stfem_vanka_plan": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "stfem_vanka_vmult": (C.c_int, [_vp, _vp, _vp, _vp]),
     "stfem_vanka_last_error": (C.c_char_p, []),
     "stfem_fe_time_weights": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
@@ -351,6 +352,13 @@ class PreconditionVanka:
     @property
     def n_classes(self):
         return lib().stfem_vanka_n_classes(self._h)
+
+    @property
+    def plan(self):
+        """(row tiles per workgroup, parts per cell block)"""
+        out = (C.c_int32 * 2)()
+        _check(lib().stfem_vanka_plan(self._h, out), "stfem_vanka_plan")
+        return tuple(out)
 
     def vmult(self, dst, src, stream=None):
         _check(lib().stfem_vanka_vmult(self._h, dst._h, src._h, stream), "stfem_vanka_vmult")

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -31,7 +32,8 @@
 namespace {
 
 constexpr int VK_MAX_BLOCKS = 8;
-constexpr int KS = 8; // k rows of the inverse staged in LDS per step (two buffers: 32 KB for a 256-row block in fp64)
+constexpr int VK_MAX_ROWS = 384; // rows of a cell block (16 x 24 tiles)
+constexpr int KS = 16; // k rows of the inverse staged in LDS per step (two buffers)
 
 struct VankaParams {
   const void *src[VK_MAX_BLOCKS];
@@ -39,8 +41,10 @@ struct VankaParams {
   const void *blocks; // [class][kpad][mpad], element (row r, column k) of the inverse at [k][r]
   const int *off;     // local node -> DoF offset from the cell's first node
   const int *cell;    // [nquad * 64]: first DoF of the cell, -1 = padding
-  const int *cls;     // [nquad]
+  const int *cls;     // [nquad]: class index | neighbour pattern << 8 (2 bits per direction: has lower, has upper)
   int nquad, m, mpad, kpad;
+  int colour;         // (cx & 1) + 2 (cy & 1) + 4 (cz & 1) of the cells of this launch
+  int p;
 };
 
 template <typename T> struct Mfma;
@@ -64,14 +68,18 @@ template <typename T, int NLOC, int MT>
 __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams prm)
 {
   using M = Mfma<T>;
-  constexpr int MPAD = 16 * MT;
-  constexpr int SR = (KS * MPAD + 255) / 256; // slab elements every thread moves
+  constexpr int MPAD = 16 * MT;               // rows this workgroup computes: [blockIdx.y MPAD, (blockIdx.y + 1) MPAD)
   __shared__ T slab[2][KS * MPAD];
   // byte offset of row r = (block, local node) of X / Y from the first source / destination block, for the cell
   // whose first DoF is 0; -1 beyond the last row.  (Indexing the kernel arguments with a lane's block number would
-  // make every gather a dependent pair of global loads.)
-  __shared__ long long s_src[MPAD], s_dst[MPAD];
-  for (int r = threadIdx.x; r < MPAD; r += 256) {
+  // make every gather a dependent pair of global loads.)  Bit 0 of a destination entry: this cell is the first of
+  // the eight colour launches to touch the DoF - it stores, the later ones add (see stfem_vanka_vmult).
+  __shared__ long long s_src[VK_MAX_ROWS], s_dst[MPAD];
+  const int row0 = blockIdx.y * MPAD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quad = blockIdx.x;
+  const int cls = prm.cls[quad] & 255, pattern = prm.cls[quad] >> 8;
+  for (int r = threadIdx.x; r < VK_MAX_ROWS; r += 256) {
     long long os = -1, od = -1;
     if (r < prm.m) {
       const int blk = r / NLOC, n = r - blk * NLOC;
@@ -82,24 +90,39 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
           os = (static_cast<const char *>(prm.src[b]) - static_cast<const char *>(prm.src[0])) + o;
           od = (static_cast<char *>(prm.dst[b]) - static_cast<char *>(prm.dst[0])) + o;
         }
+      // a DoF on a face shared with a neighbour is first touched by the cell whose colour bit is 0 in every
+      // shared direction (the launches run in ascending colour order)
+      const int np = prm.p + 1;
+      const int idx[3] = {n % np, (n / np) % np, n / (np * np)};
+      bool first = true;
+#pragma unroll
+      for (int dd = 0; dd < 3; ++dd) {
+        const int k = (pattern >> (2 * dd)) & 3;
+        const bool shared = (idx[dd] == 0 && (k & 1)) || (idx[dd] == prm.p && (k & 2));
+        if (shared && ((prm.colour >> dd) & 1)) first = false;
+      }
+      if (first) od |= 1;
     }
     s_src[r] = os;
-    s_dst[r] = od;
+    if (r >= row0 && r < row0 + MPAD) s_dst[r - row0] = od;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int quad = blockIdx.x;
-  const T *Binv = static_cast<const T *>(prm.blocks) + size_t(prm.cls[quad]) * prm.kpad * MPAD;
+  // the inverse of this class, [kpad][mpad] with mpad = all row tiles; this workgroup's MPAD columns of every k row
+  const T *Binv = static_cast<const T *>(prm.blocks) + size_t(cls) * prm.kpad * prm.mpad + row0;
   const int base = prm.cell[(quad * 4 + wave) * 16 + (lane & 15)]; // this lane's cell (column of X and Y)
   const char *src0 = static_cast<const char *>(prm.src[0]) + (long long)(base < 0 ? 0 : base) * (long long)sizeof(T);
   char *dst0 = static_cast<char *>(prm.dst[0]) + (long long)(base < 0 ? 0 : base) * (long long)sizeof(T);
   // rows [s KS, (s + 1) KS) of the (padded) inverse: fetched into registers while the previous slab is
-  // multiplied, written to the other LDS buffer afterwards
+  // multiplied, written to the other LDS buffer afterwards.  (global_load_lds_dwordx4 straight into LDS - no
+  // registers, no ds_write - measured 3-10 % SLOWER here: profiles/r2/vanka.)
+  constexpr int SR = (KS * MPAD + 255) / 256; // slab elements every thread moves
   T sreg[SR];
   auto fetch = [&](int s) {
-    const T *g = Binv + size_t(s) * KS * MPAD + threadIdx.x;
+    const T *g = Binv + size_t(s) * KS * prm.mpad;
 #pragma unroll
-    for (int q = 0; q < SR; ++q)
-      if (KS * MPAD % 256 == 0 || q * 256 + int(threadIdx.x) < KS * MPAD) sreg[q] = g[q * 256];
+    for (int q = 0; q < SR; ++q) {
+      const int e = q * 256 + int(threadIdx.x); // element (k row e / MPAD, column e % MPAD) of the slab
+      if (KS * MPAD % 256 == 0 || e < KS * MPAD) sreg[q] = g[(e / MPAD) * prm.mpad + e % MPAD];
+    }
   };
   auto deposit = [&](int buf) {
 #pragma unroll
@@ -113,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   int krow = lane >> 4;
   auto gather = [&]() -> T {
     T v = T(0);
-    if (krow < MPAD) {
+    if (krow < VK_MAX_ROWS) {
       const long long o = s_src[krow];
       if (base >= 0 && o >= 0) v = *reinterpret_cast<const T *>(src0 + o);
     }
@@ -148,20 +171,23 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
     }
     __syncthreads();
   }
-  // scatter: rows of Y back to the DoFs of the cell (cells of one launch share none)
-  if (base >= 0) {
+  // scatter: rows of Y back to the DoFs of the cell (cells of one launch share none).  All loads first
+  // (first touches, rows beyond the block and padding cells load nothing), then the stores.
+  T *d[MT * 4];
+  T old[MT * 4];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * t + M::row(lane, r);
-        const long long o = s_dst[row];
-        if (o >= 0) {
-          T *d = reinterpret_cast<T *>(dst0 + o);
-          *d += acc[t][r];
-        }
-      }
-  }
+    for (int r = 0; r < 4; ++r) {
+      const long long o = s_dst[16 * t + M::row(lane, r)];
+      d[4 * t + r] = (base >= 0 && o >= 0) ? reinterpret_cast<T *>(dst0 + (o & ~1ll)) : nullptr;
+      old[4 * t + r] = (d[4 * t + r] && !(o & 1)) ? *d[4 * t + r] : T(0);
+    }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (d[4 * t + r]) *d[4 * t + r] = old[4 * t + r] + acc[t][r];
 }
 
 // in-place Gauss-Jordan inverse with partial pivoting (FullMatrix::gauss_jordan, stmg.h:828)
@@ -200,7 +226,7 @@ thread_local char g_vanka_err[256] = "";
 
 struct stfem_vanka {
   stfem_ctx *ctx = nullptr;
-  int nb = 0, nloc = 0, m = 0, mt = 0, mpad = 0, kpad = 0, nclasses = 0;
+  int nb = 0, nloc = 0, m = 0, mt = 0, mtw = 0, parts = 0, mpad = 0, kpad = 0, nclasses = 0;
   void *d_blocks = nullptr;
   int *d_off = nullptr;
   int *d_cell[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -217,36 +243,56 @@ struct stfem_vanka {
     }                                                                                 \
   } while (0)
 
-template <typename T, int NLOC> static int vanka_launch_mt(const stfem_vanka *v, const VankaParams &prm, int nquad, hipStream_t st)
+template <typename T, int NLOC> static const void *vanka_kernel(int mtw)
 {
-  switch (v->mt) {
-#define VK_CASE(MT)                                                                                        \
-  case MT: hipLaunchKernelGGL((vanka_apply_kernel<T, NLOC, MT>), dim3(nquad), dim3(256), 0, st, prm); break;
-    VK_CASE(1) VK_CASE(2) VK_CASE(3) VK_CASE(4) VK_CASE(6) VK_CASE(8) VK_CASE(12) VK_CASE(16) VK_CASE(24)
+  switch (mtw) {
+#define VK_CASE(MT) case MT: return reinterpret_cast<const void *>(&vanka_apply_kernel<T, NLOC, MT>);
+    VK_CASE(1) VK_CASE(2) VK_CASE(3) VK_CASE(4) VK_CASE(6) VK_CASE(8)
 #undef VK_CASE
-    default: return STFEM_ERR_UNSUPPORTED;
-  }
-  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
-}
-
-template <typename T> static int vanka_launch(const stfem_vanka *v, const VankaParams &prm, int nquad, hipStream_t st)
-{
-  switch (v->ctx->p) {
-    case 1: return vanka_launch_mt<T, 8>(v, prm, nquad, st);
-    case 2: return vanka_launch_mt<T, 27>(v, prm, nquad, st);
-    case 3: return vanka_launch_mt<T, 64>(v, prm, nquad, st);
-    case 4: return vanka_launch_mt<T, 125>(v, prm, nquad, st);
-    default: return STFEM_ERR_UNSUPPORTED;
+    default: return nullptr;
   }
 }
-
-// row tiles the kernel is instantiated for (16 rows each); the block is padded up to the next one
-static int round_tiles(int mt)
+template <typename T> static const void *vanka_kernel(int p, int mtw)
 {
-  const int avail[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
-  for (int a : avail)
-    if (mt <= a) return a;
-  return 0;
+  switch (p) {
+    case 1: return vanka_kernel<T, 8>(mtw);
+    case 2: return vanka_kernel<T, 27>(mtw);
+    case 3: return vanka_kernel<T, 64>(mtw);
+    case 4: return vanka_kernel<T, 125>(mtw);
+    default: return nullptr;
+  }
+}
+static const void *vanka_kernel(const stfem_ctx *c, int mtw) { return c->prec ? vanka_kernel<float>(c->p, mtw) : vanka_kernel<double>(c->p, mtw); }
+
+static int vanka_launch(const stfem_vanka *v, VankaParams &prm, int nquad, hipStream_t st)
+{
+  const void *k = vanka_kernel(v->ctx, v->mtw);
+  if (!k) return STFEM_ERR_UNSUPPORTED;
+  void *args[] = {&prm};
+  return hipLaunchKernel(k, dim3(nquad, v->parts), dim3(256), args, 0, st) == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+
+// Row tiles (16 rows each) per workgroup: a cell block of `tiles` tiles is split into parts of mtw tiles, one
+// workgroup each (smaller parts: more workgroups per launch and per CU; larger: less set-up per MFMA).
+// Measured on cfg 1 (16 tiles): 8 and 4 tiles per workgroup within 2 % of each other, 2 tiles 10 % slower; capping
+// the resident workgroups per CU (to fill the last "round" of a colour launch) changes nothing.
+static void vanka_plan(stfem_vanka *v, int tiles)
+{
+  int env_tiles = 0;
+  if (const char *e = getenv("STFEM_VANKA_TILES")) env_tiles = atoi(e); // (experiments)
+  double best = 1e30;
+  const int cand[] = {8, 6, 4, 3, 2, 1};
+  for (int mtw : cand) {
+    if (tiles <= 4 ? mtw != tiles : mtw > tiles) continue; // small blocks: one part
+    if (env_tiles && mtw != env_tiles) continue;
+    if (!vanka_kernel(v->ctx, mtw)) continue;
+    const int parts = (tiles + mtw - 1) / mtw;
+    const double cost = double(parts * mtw) / tiles * (mtw >= 4 ? 1.0 : 1.1); // padded row tiles are computed too
+    if (cost < best - 1e-9) {
+      best = cost;
+      v->mtw = mtw; v->parts = parts; v->mt = parts * mtw;
+    }
+  }
 }
 
 extern "C" {
@@ -260,14 +306,11 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
   // one block per neighbour pattern needs identical cells: axis-aligned uniform mesh, no coefficient tables
   if (!c->cartesian || c->coef_layout[0] != 0 || c->coef_layout[1] != 0) return STFEM_ERR_UNSUPPORTED;
   const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
-  const int mt = round_tiles((m + 15) / 16);
-  if (mt == 0) return STFEM_ERR_UNSUPPORTED; // more than 384 rows per cell: Q4 with more than 3 temporal blocks
+  if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 3 temporal blocks
   VK_TRY(hipSetDevice(c->device));
   stfem_vanka *v = new (std::nothrow) stfem_vanka;
   if (!v) return STFEM_ERR_OUT_OF_MEMORY;
-  v->ctx = c; v->nb = nb; v->nloc = nloc; v->m = m; v->mt = mt;
-  v->mpad = 16 * mt;
-  v->kpad = ((m + KS - 1) / KS) * KS;
+  v->ctx = c; v->nb = nb; v->nloc = nloc; v->m = m;
 
   // 1D nodal matrices of the reference cell: Mhat = S^T W S, Khat = D^T W D
   const stfem::ShapeTables &tab = c->tab;
@@ -292,6 +335,15 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
         }
       }
   v->nclasses = int(class_key.size());
+  {
+    vanka_plan(v, (m + 15) / 16);
+    if (v->mtw == 0) {
+      delete v;
+      return STFEM_ERR_UNSUPPORTED;
+    }
+    v->mpad = 16 * v->mt;
+    v->kpad = ((m + KS - 1) / KS) * KS;
+  }
   const size_t bsz = size_t(v->kpad) * v->mpad;
   std::vector<double> all(bsz * v->nclasses, 0.0);
   for (int ci = 0; ci < v->nclasses; ++ci) {
@@ -390,7 +442,7 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
       std::vector<int> &l = by_class[ci];
       if (l.empty()) continue;
       l.resize(((l.size() + 63) / 64) * 64, -1);
-      for (size_t q = 0; q < l.size() / 64; ++q) cls.push_back(ci);
+      for (size_t q = 0; q < l.size() / 64; ++q) cls.push_back(ci | (class_key[ci] << 8));
       cells.insert(cells.end(), l.begin(), l.end());
     }
     v->nquad[colour] = int(cls.size());
@@ -421,6 +473,12 @@ void stfem_vanka_destroy(stfem_vanka *v)
 }
 
 int stfem_vanka_n_classes(const stfem_vanka *v) { return v ? v->nclasses : 0; }
+int stfem_vanka_plan(const stfem_vanka *v, int32_t out[2])
+{
+  if (!v || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  out[0] = v->mtw; out[1] = v->parts;
+  return STFEM_OK;
+}
 
 int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream)
 {
@@ -432,7 +490,7 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
   stfem_ctx *c = v->ctx;
   VK_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int i = 0; i < v->nb; ++i) VK_TRY(hipMemsetAsync(dst->blk[i], 0, size_t(c->ndofs) * c->es, st)); // dst = 0 (stmg.h:836)
+  // dst = 0 (stmg.h:836) is not a pass of its own: the first cell to touch a DoF stores (every DoF has one)
   VankaParams prm;
   std::memset(&prm, 0, sizeof(prm));
   for (int i = 0; i < v->nb; ++i) {
@@ -442,13 +500,15 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
   prm.blocks = v->d_blocks;
   prm.off = v->d_off;
   prm.m = v->m; prm.mpad = v->mpad; prm.kpad = v->kpad;
+  prm.p = c->p;
   (void)hipGetLastError();
   for (int colour = 0; colour < 8; ++colour) {
     if (v->nquad[colour] == 0) continue;
     prm.cell = v->d_cell[colour];
     prm.cls = v->d_cls[colour];
     prm.nquad = v->nquad[colour];
-    const int rc = c->prec ? vanka_launch<float>(v, prm, prm.nquad, st) : vanka_launch<double>(v, prm, prm.nquad, st);
+    prm.colour = colour;
+    const int rc = vanka_launch(v, prm, prm.nquad, st);
     if (rc != STFEM_OK) {
       snprintf(g_vanka_err, sizeof(g_vanka_err), "vanka_apply_kernel: %s", hipGetErrorString(hipGetLastError()));
       return rc;

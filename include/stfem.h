@@ -200,6 +200,8 @@ typedef struct stfem_vanka stfem_vanka;
 int stfem_vanka_create(stfem_ctx *ctx, int n, const double *alpha, const double *beta, stfem_vanka **out);
 void stfem_vanka_destroy(stfem_vanka *v);
 int stfem_vanka_n_classes(const stfem_vanka *v); /* distinct cell blocks held */
+/* diagnostics: {row tiles (16 rows) per workgroup, parts per cell block} */
+int stfem_vanka_plan(const stfem_vanka *v, int32_t out[2]);
 int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream);
 const char *stfem_vanka_last_error(void);
 

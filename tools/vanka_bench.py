@@ -38,6 +38,6 @@ m = nb * (p + 1) ** 3
 cells = N ** 3
 flop = 2.0 * m * m * cells
 peak = 78.6 if number == "double" else 157.3
-print(f"Vanka apply Q{p} x cG({r}) ({m} x {m} blocks, {V.n_classes} classes), {N}^3 cells, {number}: set-up {setup:.2f} s, "
+print(f"Vanka apply Q{p} x cG({r}) ({m} x {m} blocks, {V.n_classes} classes, plan {V.plan}), {N}^3 cells, {number}: set-up {setup:.2f} s, "
       f"{ms:.3f} ms per apply, {cells / ms * 1e3:.3e} cells/s, {flop / ms * 1e-9:.1f} TFLOP/s = "
       f"{flop / ms * 1e-9 / peak:.3f} of the {peak} TFLOP/s dense MFMA peak; DoF traffic {2 * nb * ctx.n_dofs * (8 if number == 'double' else 4) / ms * 1e-6:.0f} GB/s")
