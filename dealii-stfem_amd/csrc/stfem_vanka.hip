@@ -173,21 +173,26 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   }
   // scatter: rows of Y back to the DoFs of the cell (cells of one launch share none).  All loads first
   // (first touches, rows beyond the block and padding cells load nothing), then the stores.
-  T *d[MT * 4];
-  T old[MT * 4];
+  // (two row tiles = eight loads in flight per lane at a time: more only costs registers)
+  constexpr int TC = MT >= 2 ? 2 : 1;
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
+  for (int t0 = 0; t0 < MT; t0 += TC) {
+    T *d[TC * 4];
+    T old[TC * 4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long o = s_dst[16 * t + M::row(lane, r)];
-      d[4 * t + r] = (base >= 0 && o >= 0) ? reinterpret_cast<T *>(dst0 + (o & ~1ll)) : nullptr;
-      old[4 * t + r] = (d[4 * t + r] && !(o & 1)) ? *d[4 * t + r] : T(0);
-    }
+    for (int t = 0; t < TC; ++t)
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
+      for (int r = 0; r < 4; ++r) {
+        const long long o = t0 + t < MT ? s_dst[16 * (t0 + t) + M::row(lane, r)] : -1;
+        d[4 * t + r] = (base >= 0 && o >= 0) ? reinterpret_cast<T *>(dst0 + (o & ~1ll)) : nullptr;
+        old[4 * t + r] = (d[4 * t + r] && !(o & 1)) ? *d[4 * t + r] : T(0);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (d[4 * t + r]) *d[4 * t + r] = old[4 * t + r] + acc[t][r];
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (t0 + t < MT && d[4 * t + r]) *d[4 * t + r] = old[4 * t + r] + acc[t0 + t][r];
+  }
 }
 
 // in-place Gauss-Jordan inverse with partial pivoting (FullMatrix::gauss_jordan, stmg.h:828)
@@ -274,15 +279,16 @@ static int vanka_launch(const stfem_vanka *v, VankaParams &prm, int nquad, hipSt
 
 // Row tiles (16 rows each) per workgroup: a cell block of `tiles` tiles is split into parts of mtw tiles, one
 // workgroup each (smaller parts: more workgroups per launch and per CU; larger: less set-up per MFMA).
-// Measured on cfg 1 (16 tiles): 8 and 4 tiles per workgroup within 2 % of each other, 2 tiles 10 % slower; capping
-// the resident workgroups per CU (to fill the last "round" of a colour launch) changes nothing.
+// Measured on cfg 1 (16 tiles; profiles/r2/vanka): fp64 1.16 / 1.25 ms with 4 / 8 tiles per workgroup, fp32 0.74 / 0.69;
+// two or four 16-cell column batches per wave (one staged slab and one LDS read for 2 - 4 MFMAs) 1.19 - 1.47 ms: slower;
+// capping the resident workgroups per CU changes nothing.
 static void vanka_plan(stfem_vanka *v, int tiles)
 {
   int env_tiles = 0;
   if (const char *e = getenv("STFEM_VANKA_TILES")) env_tiles = atoi(e); // (experiments)
   double best = 1e30;
-  const int cand[] = {8, 6, 4, 3, 2, 1};
-  for (int mtw : cand) {
+  const int cand64[] = {4, 8, 6, 3, 2, 1}, cand32[] = {8, 4, 6, 3, 2, 1};
+  for (int mtw : (v->ctx->prec ? cand32 : cand64)) {
     if (tiles <= 4 ? mtw != tiles : mtw > tiles) continue; // small blocks: one part
     if (env_tiles && mtw != env_tiles) continue;
     if (!vanka_kernel(v->ctx, mtw)) continue;

@@ -266,6 +266,41 @@ private:
   bool alpha_is_zero, beta_is_zero;
 };
 
+// include/stmg.h:619-907 PreconditionVanka: cell-patch additive-Schwarz smoother of Alpha (x) K + Beta (x) M.
+// The reference builds it from the assembled sparse matrices K_, M_ (tests/tp_01.cc:283-321); here the blocks
+// come from the context's mesh and degree directly (what those matrices are assembled from), so the constructor
+// takes the operator instead.  vmult overwrites dst; smooth = vmult (stmg.h:881-885).
+template <typename Number> class PreconditionVanka {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  template <typename OperatorType>
+  PreconditionVanka(const OperatorType &K, const FullMatrix<Number> &Alpha, const FullMatrix<Number> &Beta) : ctx_(K.context())
+  {
+    if (Alpha.m() != Alpha.n() || Beta.m() != Alpha.m() || Beta.n() != Alpha.n()) throw std::invalid_argument("Alpha/Beta must be square and of one size");
+    std::vector<double> a(size_t(Alpha.m()) * Alpha.n()), b(a.size());
+    for (size_t i = 0; i < a.size(); ++i) {
+      a[i] = double(Alpha.data()[i]);
+      b[i] = double(Beta.data()[i]);
+    }
+    stfem_vanka *v = nullptr;
+    const int rc = stfem_vanka_create(ctx_->h, int(Alpha.m()), a.data(), b.data(), &v);
+    if (rc != STFEM_OK) throw Error(rc, std::string("stfem_vanka_create: ") + stfem_vanka_last_error());
+    v_.reset(v, stfem_vanka_destroy);
+  }
+  void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    const int rc = stfem_vanka_vmult(v_.get(), dst.handle(), src.handle(), stream);
+    if (rc != STFEM_OK) throw Error(rc, std::string("PreconditionVanka::vmult: ") + stfem_vanka_last_error());
+  }
+  void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
+  void clear() { v_.reset(); }
+  int n_classes() const { return stfem_vanka_n_classes(v_.get()); }
+
+private:
+  std::shared_ptr<Context> ctx_;
+  std::shared_ptr<stfem_vanka> v_;
+};
+
 // include/operators.h:1953-2050 PDE<>: the nonlinear-solver face of an operator.  residual = rhs - form(src);
 // form falls back to vmult for operators without one (internal::has_form, 1999-2004); vmult applies the
 // Jacobian operator (the same object unless given separately).

@@ -84,6 +84,14 @@ template <typename Number> int run(int argc, char **argv)
       dki.copy_from_host({di.copy_to_host()});
     }
 
+    // the smoother (stmg.h:619-907): one sweep of the cell-patch Vanka on x
+    BlockVectorT<Number> sm;
+    matrix.initialize_dof_vector(sm);
+    {
+      PreconditionVanka<Number> vanka(K_mf, Alpha, Beta);
+      vanka.smooth(sm, x);
+    }
+
     // error behaviour: aliasing and shape mismatch must throw
     int thrown = 0;
     try { matrix.vmult(x, x); } catch (const Error &e) { thrown += e.status == STFEM_ERR_ALIAS; }
@@ -102,6 +110,7 @@ template <typename Number> int run(int argc, char **argv)
       for (const auto &b : vec) std::fwrite(b.data(), sizeof(double), n, f);
     for (const auto &vec : {dk.copy_to_host(), dki.copy_to_host()})
       for (const auto &b : vec) std::fwrite(b.data(), sizeof(double), n, f);
+    for (const auto &b : sm.copy_to_host()) std::fwrite(b.data(), sizeof(double), n, f);
     std::fclose(f);
     std::printf("m=%llu blocks=%llu exceptions=%d\n", matrix.m(), nb, thrown);
     return thrown == 3 ? 0 : 4;

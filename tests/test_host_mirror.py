@@ -42,7 +42,8 @@ def test_cpp_caller_matches_oracle(case, number, tmp_path, oracle_mod):
     flat = np.fromfile(out, dtype=np.float64, offset=16)
     data = flat[:9 * nb * n].reshape(9, nb, n)
     X, Y, YT, RHS, RES0, RES1, YJ, DIAG, DINV = data
-    DK, DKI = flat[9 * nb * n:].reshape(2, n)
+    DK, DKI = flat[9 * nb * n:9 * nb * n + 2 * n].reshape(2, n)
+    SM = flat[9 * nb * n + 2 * n:].reshape(nb, n)
     Alpha, Beta, Gamma, Zeta = stfem.get_fe_time_weights(ttype, r, 1.0 / 32, ns)
     verts = stfem.mesh_vertices(nc)
     orc = oracle_mod.Oracle(p, nc, verts, 63)
@@ -64,6 +65,10 @@ def test_cpp_caller_matches_oracle(case, number, tmp_path, oracle_mod):
     for i in range(nb):
         assert rel(DIAG[i], Alpha[i, i] * dK + Beta[i, i] * dM) < tol
         assert rel(DINV[i], inv(dK) / Alpha[i, i] + inv(dM) / Beta[i, i]) < 10 * tol
+    # PreconditionVanka (stmg.h:619-907) from the C++ mirror against the numpy restatement
+    from oracle import vanka_oracle
+    want = vanka_oracle.VankaOracle(p, nc, verts, 63, Alpha, Beta).vmult(X)
+    assert rel(SM, want) < (1e-10 if number == "double" else 2e-4)
 
 
 @pytest.mark.gpu
