@@ -522,6 +522,17 @@ template <class PR> static int ensure_metric(stfem_ctx *c, bool use_lap, bool us
   return STFEM_OK;
 }
 
+// for the other translation units of the library (stfem_internal.h): the stored metric in the record layout,
+// built with the coefficient tables in force (what K and M of a SystemMatrix see)
+int stfem_internal_metric(stfem_ctx *c, const void **metric, void *stream)
+{
+  const bool lap = c->coef_layout[1] != 0, mass = c->coef_layout[0] != 0;
+  const int rc = c->prec ? ensure_metric<Prec32>(c, lap, mass, static_cast<hipStream_t>(stream))
+                         : ensure_metric<Prec64>(c, lap, mass, static_cast<hipStream_t>(stream));
+  if (rc == STFEM_OK) *metric = c->d_metric;
+  return rc;
+}
+
 // a(j,i), b(j,i): effective nbo x nbi matrices (row-major)
 template <class PR>
 static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,

@@ -47,3 +47,7 @@ struct stfem_vec {
   std::vector<void *> blk; // device arrays of the context's element type
 };
 
+
+// stfem_capi.hip: (re)builds the per-quadrature-point metric records [cell][qz][qy][qx][8] =
+// (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad) with the coefficient tables in force; element type = the context's Number
+int stfem_internal_metric(stfem_ctx *c, const void **metric, void *stream);

@@ -15,7 +15,8 @@
 // with the gather and the scatter fused in: MFMA work (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32,
 // 125 kflop against 4 kB of DoF traffic per cell).  Cells are processed in eight colours (cells of one
 // colour share no DoF), so the scatter is plain load-add-store: no atomics, bitwise reproducible.
-// General meshes and non-constant coefficients need per-cell blocks: not built (STFEM_ERR_UNSUPPORTED).
+// General meshes and coefficient tables get one block per cell (the reference's layout): set-up on the host
+// from device-computed cell matrices, apply = one HBM-bound block-times-vector per cell (vanka_apply_percell_kernel).
 #include "stfem_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -195,6 +196,108 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   }
 }
 
+// ---- general meshes / coefficient tables: one block per cell ----
+// Cell matrices from the stored metric: K_c(a,b) = sum_q grad phi_a^T G_q grad phi_b, M_c(a,b) = sum_q Mq phi_a phi_b
+// (what MatrixFreeTools::compute_matrix gets from do_cell_integral_local on unit vectors, operators.h:1021-1033).
+// One workgroup per cell; a thread takes entries (a, b).  Set-up code: plain, not tuned.
+template <typename T>
+__global__ __launch_bounds__(256) void vanka_cell_matrices_kernel(int n, const T *__restrict__ metric,
+                                                                   const double *__restrict__ S1, const double *__restrict__ D1,
+                                                                   double *__restrict__ Kc, double *__restrict__ Mc)
+{
+  const int nloc = n * n * n;
+  extern __shared__ double sm[]; // [nloc][7] metric of the cell, [n*n] S, [n*n] D
+  double *met = sm, *S = sm + nloc * 7, *D = S + n * n;
+  const long long cell = blockIdx.x;
+  for (int i = threadIdx.x; i < nloc * 7; i += 256) met[i] = double(metric[(cell * nloc + i / 7) * 8 + i % 7]);
+  for (int i = threadIdx.x; i < n * n; i += 256) { S[i] = S1[i]; D[i] = D1[i]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nloc * nloc; e += 256) {
+    const int a = e / nloc, b = e % nloc;
+    const int ax = a % n, ay = (a / n) % n, az = a / (n * n), bx = b % n, by = (b / n) % n, bz = b / (n * n);
+    double k = 0.0, mm = 0.0;
+    for (int qz = 0; qz < n; ++qz)
+      for (int qy = 0; qy < n; ++qy)
+        for (int qx = 0; qx < n; ++qx) {
+          const double *g = met + (qx + n * (qy + n * qz)) * 7;
+          const double sax = S[qx * n + ax], say = S[qy * n + ay], saz = S[qz * n + az];
+          const double sbx = S[qx * n + bx], sby = S[qy * n + by], sbz = S[qz * n + bz];
+          const double ga[3] = {D[qx * n + ax] * say * saz, sax * D[qy * n + ay] * saz, sax * say * D[qz * n + az]};
+          const double gb[3] = {D[qx * n + bx] * sby * sbz, sbx * D[qy * n + by] * sbz, sbx * sby * D[qz * n + bz]};
+          k += ga[0] * (g[0] * gb[0] + g[1] * gb[1] + g[2] * gb[2]) + ga[1] * (g[1] * gb[0] + g[3] * gb[1] + g[4] * gb[2]) +
+               ga[2] * (g[2] * gb[0] + g[4] * gb[1] + g[5] * gb[2]);
+          mm += g[6] * sax * say * saz * sbx * sby * sbz;
+        }
+    Kc[cell * nloc * nloc + e] = k;
+    Mc[cell * nloc * nloc + e] = mm;
+  }
+}
+
+struct VankaCellParams {
+  const void *src[VK_MAX_BLOCKS];
+  void *dst[VK_MAX_BLOCKS];
+  const void *blocks; // [cell][kpad][mpad], element (row r, column k) of the cell's inverse at [k][r]
+  const int *off;
+  const int *cell;    // [ncell of this colour]: cell number
+  int m, mpad, kpad, nloc, p, colour;
+  int ncx, ncy, ncz, nx, ny;
+};
+
+// y = B_c^-1 x per cell, the block streamed from HBM once (the reference's apply: stmg.h:845-867): one workgroup per
+// cell, thread r = row r; x in LDS.  HBM-bound: kpad * mpad elements per cell against 2 m of DoF traffic.
+template <typename T>
+__global__ __launch_bounds__(256) void vanka_apply_percell_kernel(const VankaCellParams prm)
+{
+  __shared__ T xs[VK_MAX_ROWS];
+  const int cell = prm.cell[blockIdx.x];
+  const int cx = cell % prm.ncx, cy = (cell / prm.ncx) % prm.ncy, cz = cell / (prm.ncx * prm.ncy);
+  const long long base = (long long)prm.p * cx + (long long)prm.nx * ((long long)prm.p * cy + (long long)prm.ny * prm.p * cz);
+  for (int r = threadIdx.x; r < prm.kpad; r += 256) {
+    T v = T(0);
+    if (r < prm.m) {
+      const int blk = r / prm.nloc, n = r - blk * prm.nloc;
+      const T *sp = static_cast<const T *>(prm.src[0]);
+#pragma unroll
+      for (int b = 1; b < VK_MAX_BLOCKS; ++b)
+        if (b == blk) sp = static_cast<const T *>(prm.src[b]);
+      v = sp[base + prm.off[n]];
+    }
+    xs[r] = v;
+  }
+  __syncthreads();
+  const T *B = static_cast<const T *>(prm.blocks) + (size_t)cell * prm.kpad * prm.mpad;
+  for (int r = threadIdx.x; r < prm.m; r += 256) {
+    T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+    const T *col = B + r;
+    int k = 0;
+    for (; k + 3 < prm.kpad; k += 4) {
+      a0 = fma(col[(size_t)k * prm.mpad], xs[k], a0);
+      a1 = fma(col[(size_t)(k + 1) * prm.mpad], xs[k + 1], a1);
+      a2 = fma(col[(size_t)(k + 2) * prm.mpad], xs[k + 2], a2);
+      a3 = fma(col[(size_t)(k + 3) * prm.mpad], xs[k + 3], a3);
+    }
+    for (; k < prm.kpad; ++k) a0 = fma(col[(size_t)k * prm.mpad], xs[k], a0);
+    const T y = (a0 + a1) + (a2 + a3);
+    const int blk = r / prm.nloc, n = r - blk * prm.nloc;
+    T *dp = static_cast<T *>(prm.dst[0]);
+#pragma unroll
+    for (int b = 1; b < VK_MAX_BLOCKS; ++b)
+      if (b == blk) dp = static_cast<T *>(prm.dst[b]);
+    // first touch (lowest colour among the cells sharing the DoF) stores, the others add
+    const int np = prm.p + 1;
+    const int idx[3] = {n % np, (n / np) % np, n / (np * np)};
+    const int cc[3] = {cx, cy, cz}, nc[3] = {prm.ncx, prm.ncy, prm.ncz};
+    bool first = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool shared = (idx[d] == 0 && cc[d] > 0) || (idx[d] == prm.p && cc[d] < nc[d] - 1);
+      if (shared && ((prm.colour >> d) & 1)) first = false;
+    }
+    T *q = dp + base + prm.off[n];
+    *q = first ? y : *q + y;
+  }
+}
+
 // in-place Gauss-Jordan inverse with partial pivoting (FullMatrix::gauss_jordan, stmg.h:828)
 bool invert(int n, std::vector<double> &A)
 {
@@ -237,6 +340,8 @@ struct stfem_vanka {
   int *d_cell[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int *d_cls[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int nquad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool per_cell = false; // one block per cell (general meshes, coefficient tables): d_blocks is [cell][kpad][mpad]
+  int ncol[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // cells per colour (d_cell[colour] = their numbers)
 };
 
 #define VK_TRY(call)                                                                  \
@@ -301,6 +406,165 @@ static void vanka_plan(stfem_vanka *v, int tiles)
   }
 }
 
+// Set-up of the per-cell blocks (general meshes, coefficient tables): cell matrices on the device from the stored
+// metric, then on the host the reference's steps one by one (stmg.h:786-829, compute_block_matrix.h:50-139):
+// restriction of the assembled matrices to the cell's DoFs (= the cell's own matrix + what the neighbours add on
+// shared faces, edges and vertices), zero-boundary rows / columns, valence scaling, Kronecker with Alpha / Beta,
+// Gauss-Jordan.  Meant for the mesh sizes the reference can hold too (one (n_blocks nloc)^2 block per cell).
+static int vanka_create_per_cell(stfem_vanka *v, const double *Alpha, const double *Beta)
+{
+  stfem_ctx *c = v->ctx;
+  const int p = c->p, n = p + 1, nloc = v->nloc, m = v->m, nb = v->nb;
+  v->per_cell = true;
+  v->mt = (m + 15) / 16;
+  v->mpad = 16 * v->mt;
+  v->kpad = ((m + 3) / 4) * 4;
+  const size_t bsz = size_t(v->kpad) * v->mpad;
+  if (double(c->ncells) * double(bsz) * double(c->es) > 64e9) {
+    snprintf(g_vanka_err, sizeof(g_vanka_err), "per-cell blocks of %lld cells need %.1f GB", (long long)c->ncells,
+             double(c->ncells) * double(bsz) * double(c->es) * 1e-9);
+    return STFEM_ERR_OUT_OF_MEMORY;
+  }
+  // ---- cell matrices
+  const void *metric = nullptr;
+  int rc = stfem_internal_metric(c, &metric, nullptr);
+  if (rc != STFEM_OK) return rc;
+  const size_t nmat = size_t(c->ncells) * nloc * nloc;
+  double *d_tab = nullptr, *d_K = nullptr, *d_M = nullptr;
+  std::vector<double> tabs(2 * n * n);
+  for (int i = 0; i < n * n; ++i) { tabs[i] = c->tab.S[i]; tabs[n * n + i] = c->tab.D[i]; }
+  auto cleanup = [&]() {
+    if (d_tab) (void)hipFree(d_tab);
+    if (d_K) (void)hipFree(d_K);
+    if (d_M) (void)hipFree(d_M);
+  };
+  if (hipMalloc(&d_tab, tabs.size() * sizeof(double)) != hipSuccess || hipMalloc(&d_K, nmat * sizeof(double)) != hipSuccess ||
+      hipMalloc(&d_M, nmat * sizeof(double)) != hipSuccess) {
+    cleanup();
+    return STFEM_ERR_OUT_OF_MEMORY;
+  }
+  std::vector<double> Kc(nmat), Mc(nmat);
+  {
+    hipError_t e = hipMemcpy(d_tab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice);
+    const size_t lds = (size_t(nloc) * 7 + 2 * n * n) * sizeof(double);
+    if (e == hipSuccess) {
+      if (c->prec)
+        hipLaunchKernelGGL(vanka_cell_matrices_kernel<float>, dim3((unsigned)c->ncells), dim3(256), lds, 0, n,
+                           static_cast<const float *>(metric), d_tab, d_tab + n * n, d_K, d_M);
+      else
+        hipLaunchKernelGGL(vanka_cell_matrices_kernel<double>, dim3((unsigned)c->ncells), dim3(256), lds, 0, n,
+                           static_cast<const double *>(metric), d_tab, d_tab + n * n, d_K, d_M);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(Kc.data(), d_K, nmat * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(Mc.data(), d_M, nmat * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) {
+      snprintf(g_vanka_err, sizeof(g_vanka_err), "cell matrices: %s", hipGetErrorString(e));
+      return STFEM_ERR_HIP;
+    }
+  }
+  // ---- blocks
+  const int ncx = c->nc[0], ncy = c->nc[1], ncz = c->nc[2];
+  std::vector<double> Kr(size_t(nloc) * nloc), Mr(size_t(nloc) * nloc), B(size_t(m) * m), val(nloc);
+  std::vector<char> cn(nloc);
+  std::vector<float> out32;
+  std::vector<double> out64;
+  if (c->prec) out32.assign(size_t(c->ncells) * bsz, 0.0f);
+  else out64.assign(size_t(c->ncells) * bsz, 0.0);
+  for (int cz = 0; cz < ncz; ++cz)
+    for (int cy = 0; cy < ncy; ++cy)
+      for (int cx = 0; cx < ncx; ++cx) {
+        const int cc[3] = {cx, cy, cz};
+        const size_t cell = cx + size_t(ncx) * (cy + size_t(ncy) * cz);
+        for (int a = 0; a < nloc; ++a) {
+          const int ia[3] = {a % n, (a / n) % n, a / (n * n)};
+          double vv = 1.0;
+          bool con = false;
+          for (int d = 0; d < 3; ++d) {
+            if ((ia[d] == 0 && cc[d] > 0) || (ia[d] == p && cc[d] < c->nc[d] - 1)) vv *= 2.0;
+            if ((ia[d] == 0 && cc[d] == 0 && (c->dmask & (1 << (2 * d)))) || (ia[d] == p && cc[d] == c->nc[d] - 1 && (c->dmask & (2 << (2 * d)))))
+              con = true;
+          }
+          val[a] = vv;
+          cn[a] = con;
+          for (int b = 0; b < nloc; ++b) {
+            const int ib[3] = {b % n, (b / n) % n, b / (n * n)};
+            // cells holding both DoFs: per direction the cell itself, and the neighbour across a face both lie on
+            int lo[3], hi[3];
+            for (int d = 0; d < 3; ++d) {
+              lo[d] = (ia[d] == 0 && ib[d] == 0 && cc[d] > 0) ? -1 : 0;
+              hi[d] = (ia[d] == p && ib[d] == p && cc[d] < c->nc[d] - 1) ? 1 : 0;
+            }
+            double ks = 0.0, ms = 0.0;
+            for (int sz = lo[2]; sz <= hi[2]; ++sz)
+              for (int sy = lo[1]; sy <= hi[1]; ++sy)
+                for (int sx = lo[0]; sx <= hi[0]; ++sx) {
+                  const int sh[3] = {sx, sy, sz};
+                  int a2 = 0, b2 = 0, mul = 1;
+                  for (int d = 0; d < 3; ++d) {
+                    const int ja = sh[d] == -1 ? p : (sh[d] == 1 ? 0 : ia[d]), jb = sh[d] == -1 ? p : (sh[d] == 1 ? 0 : ib[d]);
+                    a2 += ja * mul;
+                    b2 += jb * mul;
+                    mul *= n;
+                  }
+                  const size_t c2 = (cx + sx) + size_t(ncx) * ((cy + sy) + size_t(ncy) * (cz + sz));
+                  ks += Kc[(c2 * nloc + a2) * nloc + b2];
+                  ms += Mc[(c2 * nloc + a2) * nloc + b2];
+                }
+            Kr[size_t(a) * nloc + b] = ks;
+            Mr[size_t(a) * nloc + b] = ms;
+          }
+        }
+        for (int r = 0; r < nloc; ++r)
+          if (cn[r])
+            for (int q = 0; q < nloc; ++q)
+              if (q != r) {
+                Kr[size_t(r) * nloc + q] = Kr[size_t(q) * nloc + r] = 0.0;
+                Mr[size_t(r) * nloc + q] = Mr[size_t(q) * nloc + r] = 0.0;
+              }
+        for (int i = 0; i < nb; ++i)
+          for (int j = 0; j < nb; ++j)
+            for (int r = 0; r < nloc; ++r)
+              for (int q = 0; q < nloc; ++q)
+                B[size_t(i * nloc + r) * m + j * nloc + q] =
+                  val[r] * (Beta[i * nb + j] * Mr[size_t(r) * nloc + q] + Alpha[i * nb + j] * Kr[size_t(r) * nloc + q]);
+        if (!invert(m, B)) {
+          snprintf(g_vanka_err, sizeof(g_vanka_err), "singular cell block (cell %zu)", cell);
+          return STFEM_ERR_INVALID_ARGUMENT;
+        }
+        for (int r = 0; r < m; ++r)
+          for (int k = 0; k < m; ++k) {
+            if (c->prec) out32[cell * bsz + size_t(k) * v->mpad + r] = float(B[size_t(r) * m + k]);
+            else out64[cell * bsz + size_t(k) * v->mpad + r] = B[size_t(r) * m + k];
+          }
+      }
+  const void *hostp = c->prec ? static_cast<const void *>(out32.data()) : static_cast<const void *>(out64.data());
+  if (hipMalloc(&v->d_blocks, size_t(c->ncells) * bsz * c->es) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+  if (hipMemcpy(v->d_blocks, hostp, size_t(c->ncells) * bsz * c->es, hipMemcpyHostToDevice) != hipSuccess) return STFEM_ERR_HIP;
+  v->nclasses = int(c->ncells);
+  // ---- DoF offsets and the cells of every colour
+  std::vector<int> off(nloc);
+  for (int kz = 0; kz < n; ++kz)
+    for (int jy = 0; jy < n; ++jy)
+      for (int ix = 0; ix < n; ++ix) off[ix + n * (jy + n * kz)] = ix + c->nd[0] * (jy + c->nd[1] * kz);
+  if (hipMalloc(&v->d_off, nloc * sizeof(int)) != hipSuccess ||
+      hipMemcpy(v->d_off, off.data(), nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    return STFEM_ERR_HIP;
+  for (int colour = 0; colour < 8; ++colour) {
+    std::vector<int> cells;
+    for (int cz = colour >> 2; cz < ncz; cz += 2)
+      for (int cy = (colour >> 1) & 1; cy < ncy; cy += 2)
+        for (int cx = colour & 1; cx < ncx; cx += 2) cells.push_back(cx + ncx * (cy + ncy * cz));
+    v->ncol[colour] = int(cells.size());
+    if (cells.empty()) continue;
+    if (hipMalloc(&v->d_cell[colour], cells.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(v->d_cell[colour], cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+      return STFEM_ERR_HIP;
+  }
+  return STFEM_OK;
+}
+
 extern "C" {
 
 const char *stfem_vanka_last_error(void) { return g_vanka_err; }
@@ -309,14 +573,23 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
 {
   if (!c || !Alpha || !Beta || !out || nb < 1 || nb > VK_MAX_BLOCKS) return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  // one block per neighbour pattern needs identical cells: axis-aligned uniform mesh, no coefficient tables
-  if (!c->cartesian || c->coef_layout[0] != 0 || c->coef_layout[1] != 0) return STFEM_ERR_UNSUPPORTED;
   const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
   if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 3 temporal blocks
   VK_TRY(hipSetDevice(c->device));
   stfem_vanka *v = new (std::nothrow) stfem_vanka;
   if (!v) return STFEM_ERR_OUT_OF_MEMORY;
   v->ctx = c; v->nb = nb; v->nloc = nloc; v->m = m;
+  // one block per neighbour pattern needs identical cells: axis-aligned uniform mesh, no coefficient tables;
+  // everything else gets one block per cell
+  if (!c->cartesian || c->coef_layout[0] != 0 || c->coef_layout[1] != 0) {
+    const int rc = vanka_create_per_cell(v, Alpha, Beta);
+    if (rc != STFEM_OK) {
+      stfem_vanka_destroy(v);
+      return rc;
+    }
+    *out = v;
+    return STFEM_OK;
+  }
 
   // 1D nodal matrices of the reference cell: Mhat = S^T W S, Khat = D^T W D
   const stfem::ShapeTables &tab = c->tab;
@@ -497,6 +770,32 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
   VK_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   // dst = 0 (stmg.h:836) is not a pass of its own: the first cell to touch a DoF stores (every DoF has one)
+  if (v->per_cell) {
+    VankaCellParams cp;
+    std::memset(&cp, 0, sizeof(cp));
+    for (int i = 0; i < v->nb; ++i) {
+      cp.src[i] = src->blk[i];
+      cp.dst[i] = dst->blk[i];
+    }
+    cp.blocks = v->d_blocks;
+    cp.off = v->d_off;
+    cp.m = v->m; cp.mpad = v->mpad; cp.kpad = v->kpad; cp.nloc = v->nloc; cp.p = c->p;
+    cp.ncx = c->nc[0]; cp.ncy = c->nc[1]; cp.ncz = c->nc[2]; cp.nx = c->nd[0]; cp.ny = c->nd[1];
+    (void)hipGetLastError();
+    for (int colour = 0; colour < 8; ++colour) {
+      if (v->ncol[colour] == 0) continue;
+      cp.cell = v->d_cell[colour];
+      cp.colour = colour;
+      if (c->prec) hipLaunchKernelGGL(vanka_apply_percell_kernel<float>, dim3(v->ncol[colour]), dim3(256), 0, st, cp);
+      else hipLaunchKernelGGL(vanka_apply_percell_kernel<double>, dim3(v->ncol[colour]), dim3(256), 0, st, cp);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        snprintf(g_vanka_err, sizeof(g_vanka_err), "vanka_apply_percell_kernel: %s", hipGetErrorString(e));
+        return STFEM_ERR_HIP;
+      }
+    }
+    return STFEM_OK;
+  }
   VankaParams prm;
   std::memset(&prm, 0, sizeof(prm));
   for (int i = 0; i < v->nb; ++i) {

@@ -192,9 +192,9 @@ int stfem_dot_global(stfem_ctx *ctx, stfem_comm *comm, const stfem_vec *a, const
 /* Cell-patch Vanka / additive-Schwarz smoother of the space-time system A = Alpha (x) K + Beta (x) M:
  * PreconditionVanka (include/stmg.h:619-907; set-up 786-829 with compute_block_matrix.h:50-139, apply
  * 832-872).  create: builds and inverts the valence-weighted cell blocks of the ASSEMBLED matrices (zero
- * boundary constraints as in tests/tp_01.cc:283-299); Alpha, Beta are n x n row-major.  This round: one
- * rank, axis-aligned uniform meshes without coefficient tables (one block per neighbour pattern, at most 27);
- * other contexts return STFEM_ERR_UNSUPPORTED.  vmult: dst = sum over cells of scatter(B_c^-1 gather(src)),
+ * boundary constraints as in tests/tp_01.cc:283-299); Alpha, Beta are n x n row-major.  One rank.  Axis-aligned
+ * uniform meshes without coefficient tables hold one block per neighbour pattern (at most 27); every other
+ * context one block per cell (host-side set-up: STFEM_ERR_OUT_OF_MEMORY beyond 64 GB of blocks).  vmult: dst = sum over cells of scatter(B_c^-1 gather(src)),
  * dst is overwritten, dst must not alias src (as in the reference). */
 typedef struct stfem_vanka stfem_vanka;
 int stfem_vanka_create(stfem_ctx *ctx, int n, const double *alpha, const double *beta, stfem_vanka **out);

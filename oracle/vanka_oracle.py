@@ -24,7 +24,7 @@ from . import oracle as _o
 
 
 class VankaOracle:
-    def __init__(self, p, ncell, vertices, dirichlet_mask, Alpha, Beta):
+    def __init__(self, p, ncell, vertices, dirichlet_mask, Alpha, Beta, coef_lap=None, coef_mass=None):
         self.p, self.nc = p, tuple(ncell)
         self.Alpha, self.Beta = np.asarray(Alpha, float), np.asarray(Beta, float)
         n = p + 1
@@ -32,6 +32,10 @@ class VankaOracle:
         N = nd[0] * nd[1] * nd[2]
         self.N, self.nd = N, nd
         free = _o.Oracle(p, self.nc, vertices, 0)  # unconstrained assembly
+        if coef_lap is not None:
+            free.set_coefficient(1, coef_lap)  # (operators.h:1060-1087: the coefficient replaces the scaling)
+        if coef_mass is not None:
+            free.set_coefficient(0, coef_mass)
         K, M = free.dense(laplace=1.0), free.dense(mass=1.0)
         # constrained DoFs: rows / columns dropped, the diagonal of the unconstrained assembly stays
         con = np.zeros(nd[::-1], bool)  # [z][y][x]

@@ -50,10 +50,45 @@ def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, number):
         V.vmult(src, src)
 
 
-def test_vanka_unsupported_contexts():
+@pytest.mark.parametrize("number", ["double", "float"])
+@pytest.mark.parametrize("p,nc,ttype,r,mask,distort,coef", [
+    (2, (3, 3, 2), 0, 2, 63, 0.12, None),        # perturbed mesh
+    (4, (2, 2, 2), 0, 2, 63, 0.1, None),         # 250 x 250 blocks, one per cell
+    (3, (3, 2, 3), 1, 1, 63 & ~12, 0.0, "cell"),  # Cartesian mesh, discontinuous laplace coefficient (cfg 3's setting)
+    (2, (2, 3, 2), 0, 1, 63, 0.1, "q"),          # per-quadrature-point coefficient on a perturbed mesh
+])
+def test_vanka_per_cell_blocks_vs_oracle(p, nc, ttype, r, mask, distort, coef, number):
+    """General meshes and coefficient tables: one block per cell (set-up from device-computed cell matrices,
+    HBM-streaming apply), against the same dense restatement."""
+    from oracle import vanka_oracle
     stfem = importlib.import_module("dealii-stfem_amd")
-    nc = (2, 2, 2)
-    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
-    ctx = stfem.MatrixFreeOperator(2, nc, vertices=stfem.mesh_vertices(nc, distort=0.1, seed=3))
-    with pytest.raises(stfem.StfemError):
-        stfem.PreconditionVanka(ctx, Alpha, Beta)  # per-cell blocks are not built yet
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(ttype, r, 0.05, 1)
+    nb = Alpha.shape[0]
+    verts = stfem.mesh_vertices(nc, distort=distort, seed=11)
+    ctx = (stfem.MatrixFreeOperator(p, nc, vertices=verts, number=number, dirichlet_mask=mask) if distort else
+           stfem.MatrixFreeOperator(p, nc, number=number, dirichlet_mask=mask))
+    ncells, nq = nc[0] * nc[1] * nc[2], (p + 1) ** 3
+    rng = np.random.default_rng(2)
+    cl = None
+    if coef == "cell":
+        cc = rng.choice([1.0, 9.0, 16.0], ncells)
+        ctx.evaluate_coefficient(cc, which=1)
+        cl = np.repeat(cc, nq)  # the oracle takes one value per (cell, quadrature point)
+    elif coef == "q":
+        cl = rng.uniform(0.5, 2.0, ncells * nq)
+        ctx.evaluate_coefficient(cl.reshape(ncells, nq), which=1)
+    if number == "float" and cl is not None:
+        cl = cl.astype(np.float32).astype(np.float64)
+    V = stfem.PreconditionVanka(ctx, Alpha, Beta)
+    assert V.n_classes == ncells
+    ref = vanka_oracle.VankaOracle(p, nc, verts, mask, Alpha, Beta, coef_lap=cl)
+    X = rng.uniform(-1, 1, (nb, ctx.n_dofs))
+    if number == "float":
+        X = X.astype(np.float32).astype(np.float64)
+    src = stfem.BlockVector(ctx, nb).upload(X)
+    dst = stfem.BlockVector(ctx, nb).upload(rng.uniform(-1, 1, (nb, ctx.n_dofs)))  # overwritten
+    V.vmult(dst, src)
+    Y = dst.download()
+    assert rel(Y, ref.vmult(X)) < (1e-10 if number == "double" else 5e-4)
+    V.vmult(dst, src)
+    assert np.array_equal(dst.download(), Y)
