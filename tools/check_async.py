@@ -131,6 +131,20 @@ def main():
             for b in check_kernel(kname, body)[:10]:
                 print(f"{obj}: {b}")
                 failed = True
+        # tile kernels st_sweep_cart_tile<P, NBM, MINW, ADD, COEF, GEN, COLOUR>: ASYNC_LOADS = !GEN && NBM <= 3 (asm-issued
+        # src prefetch, load_plane_async): no spills allowed either (no dataflow check: their other loads are the compiler's)
+        for kname in funcs:
+            m = re.search(r"st_sweep_cart_tileILi\d+ELi(\d+)ELi\d+ELb[01]ELb[01]ELb([01])ELi[01]E", kname)
+            if not m or m.group(2) != "0" or int(m.group(1)) > 3:
+                continue
+            checked += 1
+            spills, scratch = kernels.get(kname, (None, None))
+            if spills is None:
+                print(f"{obj}: no metadata for {kname}")
+                failed = True
+            elif spills or scratch:
+                print(f"{obj}: {kname}: {spills} spilled VGPRs, {scratch} B scratch - asynchronous loads are unsafe here")
+                failed = True
         print(f"{obj}: {checked} asynchronous-load kernels checked")
     sys.exit(1 if failed else 0)
 
