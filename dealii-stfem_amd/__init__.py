@@ -91,6 +91,14 @@ SIGNATURES = {
     "stfem_halo_begin": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "stfem_halo_end": (C.c_int, [_vp, _vp, _vp, _vp]),
     "stfem_dot_global": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _dp, _vp]),
+    "stfem_support_points": (C.c_int, [_vp, _dp]),
+    "stfem_quadrature_points": (C.c_int, [_vp, C.c_int, _dp]),
+    "stfem_integrate_rhs": (C.c_int, [_vp, C.c_int, _dp, _vp, C.c_int, _vp]),
+    "stfem_integrate_difference": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _dp, _dp, _dp, _vp]),
+    "stfem_vector_axpby": (C.c_int, [_vp, C.c_double, _vp, C.c_double, _vp, _vp]),
+    "stfem_driver_last_error": (C.c_char_p, []),
+    "stfem_gauss_rule": (C.c_int, [C.c_int, _dp, _dp]),
+    "stfem_fe_time_points": (C.c_int, [C.c_int, C.c_int, _dp]),
     "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
     "stfem_vanka_destroy": (None, [_vp]),
     "stfem_vanka_n_classes": (C.c_int, [_vp]),

@@ -150,7 +150,9 @@ private:
     stfem_space_desc sd{int32_t(degree), int32_t(degree + 1), 1, std::is_same<Number, float>::value ? 1 : 0};
     stfem_ctx *c = nullptr;
     check(stfem_ctx_create(&md, &sd, &c), "stfem_ctx_create");
-    return std::make_shared<Context>(c);
+    auto ctx = std::make_shared<Context>(c);
+    ctx->degree = degree;
+    return ctx;
   }
   std::shared_ptr<Context> ctx_;
 };

@@ -1,0 +1,309 @@
+// Host-side mirror of the slab driver: the reference's TimeIntegratorFO
+// (include/time_integrators.h:30-336), the pieces of deal.II it drives (SolverFGMRES with a ReductionControl,
+// PreconditionRelaxation around the Vanka smoother) and ErrorCalculator (include/exact_solution.h:503-649),
+// on top of the C-ABI.  Everything heavy - operator, smoother, load vectors, error norms, vector arithmetic -
+// runs on the device; this file is the control flow.
+#pragma once
+#include "operators.h"
+
+#include <cmath>
+#include <functional>
+#include <vector>
+
+namespace stfem {
+
+// ---- vector arithmetic of the solver (LinearAlgebra::distributed::BlockVector::add / sadd / equ / l2_norm)
+template <typename Number> void axpby(double a, const BlockVectorT<Number> &x, double b, BlockVectorT<Number> &y)
+{
+  check(stfem_vector_axpby(x.context()->h, a, x.handle(), b, y.handle(), nullptr), "stfem_vector_axpby");
+}
+template <typename Number> double norm(const BlockVectorT<Number> &x) { return std::sqrt(dot(x, x)); }
+
+// One block of a block vector as a one-block vector of its own (a view: nothing is copied)
+template <typename Number> BlockVectorT<Number> block_view(const BlockVectorT<Number> &v, unsigned b)
+{
+  BlockVectorT<Number> out;
+  void *ptr = stfem_vector_block(v.handle(), int(b));
+  out.wrap(v.context(), &ptr, 1);
+  return out;
+}
+
+struct PreconditionIdentity {
+  template <typename V> void vmult(V &dst, const V &src) const { axpby(1.0, src, 0.0, dst); }
+};
+
+// PreconditionRelaxation (deal.II) with the Vanka smoother as inner preconditioner, as the multigrid levels of the
+// reference use it (stmg.h:1199-1238): n_iterations sweeps of x <- x + omega P^-1 (b - A x) from x = 0
+template <typename Number, typename Operator> class PreconditionRelaxation {
+public:
+  PreconditionRelaxation(const Operator &A, const PreconditionVanka<Number> &P, double omega, unsigned n_iterations)
+    : A(A), P(P), omega(omega), n_iterations(n_iterations)
+  {}
+  void vmult(BlockVectorT<Number> &dst, const BlockVectorT<Number> &src) const
+  {
+    if (!tmp.handle()) {
+      A.initialize_dof_vector(tmp);
+      A.initialize_dof_vector(res);
+    }
+    P.vmult(dst, src);
+    axpby(0.0, dst, omega, dst);
+    for (unsigned it = 1; it < n_iterations; ++it) {
+      A.vmult(res, dst);
+      axpby(1.0, src, -1.0, res); // res = src - A dst
+      P.vmult(tmp, res);
+      axpby(omega, tmp, 1.0, dst);
+    }
+  }
+
+private:
+  const Operator &A;
+  const PreconditionVanka<Number> &P;
+  double omega;
+  unsigned n_iterations;
+  mutable BlockVectorT<Number> tmp, res;
+};
+
+// deal.II SolverFGMRES with ReductionControl(max_steps, abs_tol, reduce) as the reference sets it up
+// (time_integrators.h:57-60: 200 steps, 1e-12 absolute, gmres_tolerance relative, restart 100):
+// right-preconditioned flexible GMRES, modified Gram-Schmidt, Givens rotations.
+template <typename Number> class SolverFGMRES {
+public:
+  using V = BlockVectorT<Number>;
+  SolverFGMRES(unsigned max_steps, double abs_tol, double reduce, unsigned restart = 100)
+    : max_steps(max_steps), abs_tol(abs_tol), reduce(reduce), restart(restart)
+  {}
+  unsigned last_step() const { return steps; }
+  double last_value() const { return value; }
+
+  template <typename Operator, typename Preconditioner>
+  void solve(const Operator &A, V &x, const V &b, const Preconditioner &P)
+  {
+    steps = 0;
+    V r;
+    A.initialize_dof_vector(r);
+    const unsigned nb = x.n_blocks();
+    auto fresh = [&](V &v) {
+      if (!v.handle()) v.reinit(x.context(), nb);
+    };
+    double tol = abs_tol;
+    bool first = true;
+    while (true) {
+      A.vmult(r, x);
+      axpby(1.0, b, -1.0, r);
+      double beta = norm(r);
+      if (first) {
+        tol = std::max(abs_tol, reduce * beta);
+        first = false;
+      }
+      value = beta;
+      if (beta <= tol) return;
+      if (steps >= max_steps) throw std::runtime_error("SolverFGMRES: no convergence");
+      const unsigned m = std::min(restart, max_steps - steps);
+      if (vs.size() < m + 1) { vs.resize(m + 1); zs.resize(m); }
+      std::vector<double> H(size_t(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1, 0.0);
+      fresh(vs[0]);
+      axpby(1.0 / beta, r, 0.0, vs[0]);
+      g[0] = beta;
+      unsigned j = 0;
+      for (; j < m; ++j) {
+        fresh(zs[j]);
+        fresh(vs[j + 1]);
+        P.vmult(zs[j], vs[j]);
+        A.vmult(vs[j + 1], zs[j]);
+        for (unsigned i = 0; i <= j; ++i) {
+          const double h = dot(vs[j + 1], vs[i]);
+          H[i * m + j] = h;
+          axpby(-h, vs[i], 1.0, vs[j + 1]);
+        }
+        const double hn = norm(vs[j + 1]);
+        H[(j + 1) * m + j] = hn;
+        if (hn > 0) axpby(1.0 / hn, vs[j + 1], 0.0, vs[j + 1]);
+        for (unsigned i = 0; i < j; ++i) {
+          const double t = cs[i] * H[i * m + j] + sn[i] * H[(i + 1) * m + j];
+          H[(i + 1) * m + j] = -sn[i] * H[i * m + j] + cs[i] * H[(i + 1) * m + j];
+          H[i * m + j] = t;
+        }
+        const double d = std::hypot(H[j * m + j], H[(j + 1) * m + j]);
+        cs[j] = H[j * m + j] / d;
+        sn[j] = H[(j + 1) * m + j] / d;
+        H[j * m + j] = d;
+        H[(j + 1) * m + j] = 0.0;
+        g[j + 1] = -sn[j] * g[j];
+        g[j] = cs[j] * g[j];
+        ++steps;
+        value = std::abs(g[j + 1]);
+        if (value <= tol || steps >= max_steps) {
+          ++j;
+          break;
+        }
+      }
+      // x += Z y,  H y = g
+      std::vector<double> y(j);
+      for (int i = int(j) - 1; i >= 0; --i) {
+        double s = g[i];
+        for (unsigned k = i + 1; k < j; ++k) s -= H[i * m + k] * y[k];
+        y[i] = s / H[i * m + i];
+      }
+      for (unsigned i = 0; i < j; ++i) axpby(y[i], zs[i], 1.0, x);
+      if (value <= tol) return;
+    }
+  }
+
+private:
+  unsigned max_steps;
+  double abs_tol, reduce;
+  unsigned restart, steps = 0;
+  double value = 0.0;
+  std::vector<V> vs, zs;
+};
+
+// The temporal basis: Lagrange polynomials through get_time_quad's points (fe_time.cc:152-169), evaluated at x
+inline std::vector<double> lagrange_values(const std::vector<double> &nodes, double x)
+{
+  std::vector<double> L(nodes.size(), 1.0);
+  for (size_t a = 0; a < nodes.size(); ++a)
+    for (size_t m = 0; m < nodes.size(); ++m)
+      if (m != a) L[a] *= (x - nodes[m]) / (nodes[a] - nodes[m]);
+  return L;
+}
+inline std::vector<double> time_points(TimeStepType type, unsigned r)
+{
+  std::vector<double> p(r + 1);
+  check(stfem_fe_time_points(type == TimeStepType::CGP ? 0 : 1, int(r), p.data()), "stfem_fe_time_points");
+  return p;
+}
+
+// A scalar function of (x, t) evaluated at a list of points: out[i] = f(points[3 i .. 3 i + 2], t)
+using PointFunction = std::function<void(double time, const std::vector<double> &points, std::vector<double> &out)>;
+
+// include/time_integrators.h:30-336 for one variable: rhs = rhs_matrix prev_x + time quadrature of the source,
+// FGMRES on the slab system.  Alpha / Gamma are the ONE-step temporal matrices (tests/tp_01.cc:123, 525-526).
+template <typename Number, typename System, typename RHSSystem, typename Preconditioner> class TimeIntegratorFO {
+public:
+  using V = BlockVectorT<Number>;
+  TimeIntegratorFO(TimeStepType type, unsigned time_degree, const FullMatrix<Number> &Alpha, const FullMatrix<Number> &Gamma,
+                   double gmres_tolerance, const System &matrix, const Preconditioner &preconditioner, const RHSSystem &rhs_matrix,
+                   const PointFunction &source, unsigned n_timesteps_at_once, bool extrapolate = true, double abstol = 1e-12)
+    : type(type), time_degree(time_degree), quad_time(time_points(type, time_degree)), Alpha(Alpha), Gamma(Gamma),
+      solver(200, abstol, gmres_tolerance, 100), preconditioner(preconditioner), matrix(matrix), rhs_matrix(rhs_matrix), source(source),
+      n_timesteps_at_once(n_timesteps_at_once), nt_dofs(type == TimeStepType::DG ? time_degree + 1 : time_degree), do_extrapolate(extrapolate)
+  {
+    const Context &c = *matrix_context();
+    nq = int(c.degree) + 1; // QGauss(fe degree + 1): the operator's rule (tests/tp_01.cc:95)
+    qpoints.resize(size_t(stfem_n_cells(c.h)) * nq * nq * nq * 3);
+    check(stfem_quadrature_points(c.h, nq, qpoints.data()), "stfem_quadrature_points");
+  }
+
+  // assemble_force (time_integrators.h:73-111): Alpha is diagonal (time quadrature = support points)
+  void assemble_force(V &rhs, double time, double time_step) const
+  {
+    V tmp;
+    tmp.reinit(rhs.context(), 1);
+    std::vector<double> fq;
+    for (unsigned it = 0; it < n_timesteps_at_once; ++it)
+      for (unsigned j = 0; j < quad_time.size(); ++j) {
+        const double t = time + time_step * it + time_step * quad_time[j];
+        source(t, qpoints, fq);
+        check(stfem_integrate_rhs(rhs.context()->h, nq, fq.data(), tmp.handle(), 0, nullptr), "stfem_integrate_rhs");
+        auto add = [&](unsigned block, double w) {
+          V view = block_view(rhs, block);
+          axpby(w, tmp, 1.0, view);
+        };
+        if (type == TimeStepType::DG) add(it * nt_dofs + j, Alpha(j, j));
+        else if (j == 0)
+          for (unsigned i = 0; i < nt_dofs; ++i) add(it * nt_dofs + i, -Gamma(i, 0));
+        else add(it * nt_dofs + j - 1, Alpha(j - 1, j - 1));
+      }
+  }
+
+  // solve (time_integrators.h:300-321); prev_x: one block
+  void solve(V &x, const V &prev_x, V &rhs, double time, double time_step)
+  {
+    rhs_matrix.vmult_slice(rhs, prev_x);
+    assemble_force(rhs, time, time_step);
+    for (unsigned b = 0; b < x.n_blocks(); ++b) { // extrapolate (time_integrators.h:184-194)
+      V view = block_view(x, b);
+      axpby(do_extrapolate ? 1.0 : 0.0, prev_x, 0.0, view);
+    }
+    solver.solve(matrix, x, rhs, preconditioner);
+  }
+  unsigned last_step() const { return solver.last_step(); }
+
+private:
+  std::shared_ptr<Context> matrix_context() const
+  {
+    V probe;
+    matrix.initialize_dof_vector(probe);
+    return probe.context();
+  }
+  TimeStepType type;
+  unsigned time_degree;
+  std::vector<double> quad_time;
+  const FullMatrix<Number> &Alpha, &Gamma;
+  SolverFGMRES<Number> solver;
+  const Preconditioner &preconditioner;
+  const System &matrix;
+  const RHSSystem &rhs_matrix;
+  PointFunction source;
+  unsigned n_timesteps_at_once, nt_dofs;
+  bool do_extrapolate;
+  int nq = 0;
+  std::vector<double> qpoints;
+};
+
+// include/exact_solution.h:503-649: errors of the space-time solution on one slab, QGauss(time degree + 1) in time
+// and QGauss(nq_space) per direction in space; u_h(t) from the temporal Lagrange basis (tests/tp_01.cc:404-427)
+template <typename Number> class ErrorCalculator {
+public:
+  using V = BlockVectorT<Number>;
+  ErrorCalculator(TimeStepType type, unsigned time_degree, int nq_space, const std::shared_ptr<Context> &ctx, const PointFunction &exact,
+                  const PointFunction &exact_gradient)
+    : type(type), time_degree(time_degree), nq(nq_space), ctx(ctx), exact(exact), exact_gradient(exact_gradient),
+      nodes(time_points(type, time_degree)), tq(time_degree + 1), tw(time_degree + 1)
+  {
+    check(stfem_gauss_rule(int(time_degree + 1), tq.data(), tw.data()), "stfem_gauss_rule");
+    qpoints.resize(size_t(stfem_n_cells(ctx->h)) * nq * nq * nq * 3);
+    check(stfem_quadrature_points(ctx->h, nq, qpoints.data()), "stfem_quadrature_points");
+    numeric.reinit(ctx, 1);
+  }
+  // returns {L2^2 contribution, Linfty, H1-semi^2 contribution} of the slab [time, time + n_steps * time_step]
+  std::array<double, 3> evaluate_error(double time, double time_step, const V &x, const V &prev_x, unsigned n_time_steps_at_once)
+  {
+    std::array<double, 3> err{0.0, -1.0, 0.0};
+    const unsigned nt_dofs = type == TimeStepType::DG ? time_degree + 1 : time_degree;
+    std::vector<double> ue, ge;
+    for (unsigned it = 0; it < n_time_steps_at_once; ++it)
+      for (unsigned q = 0; q < tq.size(); ++q) {
+        const double t = time + time_step * it + tq[q] * time_step;
+        const std::vector<double> L = lagrange_values(nodes, tq[q]);
+        // evaluate_numerical_solution: DG: sum_i L_i x_i; CGP: L_0 prev + sum_{i>=1} L_i x_{i-1}
+        axpby(0.0, numeric, 0.0, numeric);
+        if (type == TimeStepType::DG) {
+          for (unsigned i = 0; i < nt_dofs; ++i) axpby(L[i], block_view(x, it * nt_dofs + i), 1.0, numeric);
+        } else {
+          if (it == 0) axpby(L[0], prev_x, 1.0, numeric);
+          else axpby(L[0], block_view(x, nt_dofs * it - 1), 1.0, numeric);
+          for (unsigned i = 1; i <= time_degree; ++i) axpby(L[i], block_view(x, it * nt_dofs + i - 1), 1.0, numeric);
+        }
+        exact(t, qpoints, ue);
+        exact_gradient(t, qpoints, ge);
+        double out[3];
+        check(stfem_integrate_difference(ctx->h, nq, numeric.handle(), 0, ue.data(), ge.data(), out, nullptr), "stfem_integrate_difference");
+        err[0] += time_step * tw[q] * out[0];
+        err[1] = std::max(err[1], out[1]);
+        err[2] += time_step * tw[q] * out[2];
+      }
+    return err;
+  }
+
+private:
+  TimeStepType type;
+  unsigned time_degree;
+  int nq;
+  std::shared_ptr<Context> ctx;
+  PointFunction exact, exact_gradient;
+  std::vector<double> nodes, tq, tw, qpoints;
+  V numeric;
+};
+
+} // namespace stfem

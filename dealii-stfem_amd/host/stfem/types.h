@@ -92,6 +92,7 @@ struct Context {
   stfem_ctx *h = nullptr;
   std::shared_ptr<Communicator> comm;
   int lower_rank = -1, upper_rank = -1;
+  unsigned degree = 0; // FE_Q(degree) in space
   explicit Context(stfem_ctx *c) : h(c) {}
   ~Context() { stfem_ctx_destroy(h); }
   Context(const Context &) = delete;
@@ -149,6 +150,15 @@ public:
     nb_ = n_blocks;
     stfem_vec *v = nullptr;
     check(stfem_vector_create(ctx->h, int(n_blocks), &v), "stfem_vector_create");
+    v_.reset(v, stfem_vector_destroy);
+  }
+  // view of caller-owned device arrays (one pointer per block); nothing is copied or freed
+  void wrap(const std::shared_ptr<Context> &ctx, void *const *device_blocks, unsigned n_blocks)
+  {
+    ctx_ = ctx;
+    nb_ = n_blocks;
+    stfem_vec *v = nullptr;
+    check(stfem_vector_wrap(ctx->h, int(n_blocks), device_blocks, &v), "stfem_vector_wrap");
     v_.reset(v, stfem_vector_destroy);
   }
   unsigned n_blocks() const { return nb_; }

@@ -205,6 +205,30 @@ int stfem_vanka_plan(const stfem_vanka *v, int32_t out[2]);
 int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream);
 const char *stfem_vanka_last_error(void);
 
+/* Around the operator, for the slab driver (include/time_integrators.h, tests/tp_01.cc:382-400, 646-725,
+ * include/exact_solution.h:503-649).  The caller evaluates its functions at the points and hands the values in
+ * (host arrays); nq = points of the Gauss rule per direction (tests/tp_01.cc uses degree + 1 for the load vector,
+ * ErrorCalculator one fewer).
+ * support_points:    out[ndofs][3], the nodes in the order of the vectors (VectorTools::interpolate = evaluate + upload)
+ * quadrature_points: out[cell][q][3], q = qx + nq (qy + nq qz)
+ * integrate_rhs:     block `block` of dst = (f, phi_i) with QGauss(nq), constrained rows 0
+ *                    (VectorTools::create_right_hand_side with the zero-boundary constraints).  Synchronous.
+ * integrate_difference: out = { sum JxW (u_h - u)^2, max |u_h - u|, sum JxW |grad u_h - grad u|^2 } over the
+ *                    quadrature points (VectorTools::integrate_difference for L2_norm squared, Linfty_norm,
+ *                    H1_seminorm squared); exact_grad_at_points [cell][q][3] may be NULL (third entry 0).  Synchronous.
+ * vector_axpby:      y = a x + b y on every block (b = 0: y is overwritten, never read) */
+int stfem_support_points(const stfem_ctx *ctx, double *out);
+int stfem_quadrature_points(const stfem_ctx *ctx, int nq, double *out);
+int stfem_integrate_rhs(stfem_ctx *ctx, int nq, const double *f_at_points, stfem_vec *dst, int block, void *stream);
+int stfem_integrate_difference(stfem_ctx *ctx, int nq, const stfem_vec *u, int block, const double *exact_at_points,
+                               const double *exact_grad_at_points, double out[3], void *stream);
+int stfem_vector_axpby(stfem_ctx *ctx, double a, const stfem_vec *x, double b, stfem_vec *y, void *stream);
+const char *stfem_driver_last_error(void);
+/* QGauss(n) on [0, 1]; the support points of the temporal basis, get_time_quad (fe_time.cc:152-161): QGaussLobatto(r + 1)
+ * for cG(r) (type 0), QGaussRadau(r + 1, right) for dG(r) (type 1); r + 1 values */
+int stfem_gauss_rule(int n, double *points, double *weights);
+int stfem_fe_time_points(int type, int r, double *points);
+
 /* Host-side helpers mirroring include/fe_time.h (type: 0 = CGP, 1 = DG).  Row-major outputs,
  * nb = (type==0 ? r : r+1) * n_timesteps_at_once; returns nb or a negative status.
  * get_fe_time_weights (fe_time.h:351-409) */
