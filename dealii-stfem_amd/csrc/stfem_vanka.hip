@@ -34,6 +34,7 @@ namespace {
 
 constexpr int VK_MAX_BLOCKS = 8;
 constexpr int VK_MAX_ROWS = 384; // rows of a cell block (16 x 24 tiles)
+constexpr long long VK_NO_ROW = -0x7fffffffffffffffll - 1; // offset-table entry of a row beyond the block (pointer differences may be negative)
 constexpr int KS = 16; // k rows of the inverse staged in LDS per step (two buffers)
 
 struct VankaParams {
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   constexpr int MPAD = 16 * MT;               // rows this workgroup computes: [blockIdx.y MPAD, (blockIdx.y + 1) MPAD)
   __shared__ T slab[2][KS * MPAD];
   // byte offset of row r = (block, local node) of X / Y from the first source / destination block, for the cell
-  // whose first DoF is 0; -1 beyond the last row.  (Indexing the kernel arguments with a lane's block number would
+  // whose first DoF is 0; VK_NO_ROW beyond the last row.  (Indexing the kernel arguments with a lane's block number would
   // make every gather a dependent pair of global loads.)  Bit 0 of a destination entry: this cell is the first of
   // the eight colour launches to touch the DoF - it stores, the later ones add (see stfem_vanka_vmult).
   __shared__ long long s_src[VK_MAX_ROWS], s_dst[MPAD];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   const int quad = blockIdx.x;
   const int cls = prm.cls[quad] & 255, pattern = prm.cls[quad] >> 8;
   for (int r = threadIdx.x; r < VK_MAX_ROWS; r += 256) {
-    long long os = -1, od = -1;
+    long long os = VK_NO_ROW, od = VK_NO_ROW;
     if (r < prm.m) {
       const int blk = r / NLOC, n = r - blk * NLOC;
       const long long o = (long long)prm.off[n] * (long long)sizeof(T);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
     T v = T(0);
     if (krow < VK_MAX_ROWS) {
       const long long o = s_src[krow];
-      if (base >= 0 && o >= 0) v = *reinterpret_cast<const T *>(src0 + o);
+      if (base >= 0 && o != VK_NO_ROW) v = *reinterpret_cast<const T *>(src0 + o);
     }
     krow += 4;
     return v;
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
     for (int t = 0; t < TC; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long long o = t0 + t < MT ? s_dst[16 * (t0 + t) + M::row(lane, r)] : -1;
-        d[4 * t + r] = (base >= 0 && o >= 0) ? reinterpret_cast<T *>(dst0 + (o & ~1ll)) : nullptr;
+        const long long o = t0 + t < MT ? s_dst[16 * (t0 + t) + M::row(lane, r)] : VK_NO_ROW;
+        d[4 * t + r] = (base >= 0 && o != VK_NO_ROW) ? reinterpret_cast<T *>(dst0 + (o & ~1ll)) : nullptr;
         old[4 * t + r] = (d[4 * t + r] && !(o & 1)) ? *d[4 * t + r] : T(0);
       }
 #pragma unroll

@@ -5,9 +5,11 @@
 // (the reference preconditions with its space-time multigrid, SURVEY 8 f-2, not built: the errors do not depend
 // on the preconditioner, the iteration counts do).
 // Usage: heat_convergence <type 0 = cG | 1 = dG> <k> <refinement> <n_timesteps_at_once> [vanka sweeps = 2, 0 = none] [omega = 0.5]
-// Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve
+//                         [fe_degree = k + 1] [cells per direction = 2^refinement] [end_time = 1] [FGMRES steps = 200]
+// Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
 #include "stfem/time_integrators.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -24,9 +26,10 @@ int main(int argc, char **argv)
   const unsigned k = std::atoi(argv[2]), refinement = std::atoi(argv[3]), nsteps = std::atoi(argv[4]);
   const unsigned sweeps = argc > 5 ? std::atoi(argv[5]) : 2;
   const double omega = argc > 6 ? std::atof(argv[6]) : 0.5;
-  const unsigned fe_degree = k + 1;          // tests/tp_01.cc:76
-  const int n = 1 << refinement;             // subdivided_hyper_rectangle with one subdivision, refined globally
-  const double tau = std::ldexp(1.0, -int(refinement + 1)), end_time = 1.0, f = 1.0, PI = 3.14159265358979323846;
+  const unsigned fe_degree = argc > 7 ? std::atoi(argv[7]) : k + 1; // tests/tp_01.cc:76
+  const int n = argc > 8 ? std::atoi(argv[8]) : 1 << refinement;    // subdivided_hyper_rectangle with one subdivision, refined globally
+  const double tau = std::ldexp(1.0, -int(refinement + 1)), end_time = argc > 9 ? std::atof(argv[9]) : 1.0, f = 1.0, PI = 3.14159265358979323846;
+  const unsigned max_steps = argc > 10 ? std::atoi(argv[10]) : 200;
   try {
     Mesh mesh;
     mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = n;
@@ -73,11 +76,14 @@ int main(int argc, char **argv)
     }
     ErrorCalculator<Number> error_calculator(type, k, int(k + 1), K_mf.context(), exact, exact_grad); // exact_solution.h:524-526
 
-    double l2 = 0.0, l8 = -1.0, h1 = 0.0, time = 0.0;
+    double l2 = 0.0, l8 = -1.0, h1 = 0.0, time = 0.0, solve_s = 0.0;
     unsigned total_its = 0, solves = 0;
     auto run = [&](auto &step) {
       while (time < end_time - 1e-12) {
+        const auto t0 = std::chrono::steady_clock::now();
         step.solve(x, prev_x, rhs, time, tau);
+        (void)dot(x, x); // synchronises
+        solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         total_its += step.last_step();
         ++solves;
         const auto e = error_calculator.evaluate_error(time, tau, x, prev_x, nsteps);
@@ -91,13 +97,15 @@ int main(int argc, char **argv)
     if (sweeps > 0) {
       PreconditionVanka<Number> vanka(K_mf, Alpha, Beta);
       PreconditionRelaxation<Number, SystemN> precond(matrix, vanka, omega, sweeps);
-      TimeIntegratorFO<Number, SystemN, SystemN, decltype(precond)> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps);
+      TimeIntegratorFO<Number, SystemN, SystemN, decltype(precond)> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps, true, 1e-12, max_steps);
       run(step);
     } else {
       PreconditionIdentity precond;
-      TimeIntegratorFO<Number, SystemN, SystemN, PreconditionIdentity> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps);
+      TimeIntegratorFO<Number, SystemN, SystemN, PreconditionIdentity> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps, true, 1e-12, max_steps);
       run(step);
     }
+    std::fprintf(stderr, "%u slab solves, %u FGMRES iterations, %.3f s in solve (rhs assembly + FGMRES): %.2f ms per iteration\n", solves,
+                 total_its, solve_s, 1e3 * solve_s / std::max(1u, total_its));
     std::printf("%d %llu %u %.12e %.12e %.12e %.2f\n", n * n * n, (unsigned long long)K_mf.m(), x.n_blocks(), l8, std::sqrt(l2), std::sqrt(h1),
                 double(total_its) / solves);
   } catch (const std::exception &e) {

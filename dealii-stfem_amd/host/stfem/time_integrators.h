@@ -7,6 +7,8 @@
 #include "operators.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <vector>
 
@@ -74,6 +76,7 @@ public:
   {}
   unsigned last_step() const { return steps; }
   double last_value() const { return value; }
+  unsigned verbose = 0; // print the residual every `verbose` steps
 
   template <typename Operator, typename Preconditioner>
   void solve(const Operator &A, V &x, const V &b, const Preconditioner &P)
@@ -132,6 +135,7 @@ public:
         g[j] = cs[j] * g[j];
         ++steps;
         value = std::abs(g[j + 1]);
+        if (verbose && steps % verbose == 0) std::fprintf(stderr, "  FGMRES step %u residual %.3e (start %.3e)\n", steps, value, beta);
         if (value <= tol || steps >= max_steps) {
           ++j;
           break;
@@ -183,11 +187,13 @@ public:
   using V = BlockVectorT<Number>;
   TimeIntegratorFO(TimeStepType type, unsigned time_degree, const FullMatrix<Number> &Alpha, const FullMatrix<Number> &Gamma,
                    double gmres_tolerance, const System &matrix, const Preconditioner &preconditioner, const RHSSystem &rhs_matrix,
-                   const PointFunction &source, unsigned n_timesteps_at_once, bool extrapolate = true, double abstol = 1e-12)
+                   const PointFunction &source, unsigned n_timesteps_at_once, bool extrapolate = true, double abstol = 1e-12,
+                   unsigned max_steps = 200)
     : type(type), time_degree(time_degree), quad_time(time_points(type, time_degree)), Alpha(Alpha), Gamma(Gamma),
-      solver(200, abstol, gmres_tolerance, 100), preconditioner(preconditioner), matrix(matrix), rhs_matrix(rhs_matrix), source(source),
+      solver(max_steps, abstol, gmres_tolerance, 100), preconditioner(preconditioner), matrix(matrix), rhs_matrix(rhs_matrix), source(source),
       n_timesteps_at_once(n_timesteps_at_once), nt_dofs(type == TimeStepType::DG ? time_degree + 1 : time_degree), do_extrapolate(extrapolate)
   {
+    if (const char *e = std::getenv("STFEM_FGMRES_VERBOSE")) solver.verbose = unsigned(std::atoi(e));
     const Context &c = *matrix_context();
     nq = int(c.degree) + 1; // QGauss(fe degree + 1): the operator's rule (tests/tp_01.cc:95)
     qpoints.resize(size_t(stfem_n_cells(c.h)) * nq * nq * nq * 3);

@@ -92,3 +92,27 @@ def test_vanka_per_cell_blocks_vs_oracle(p, nc, ttype, r, mask, distort, coef, n
     assert rel(Y, ref.vmult(X)) < (1e-10 if number == "double" else 5e-4)
     V.vmult(dst, src)
     assert np.array_equal(dst.download(), Y)
+
+
+def test_vanka_blocks_at_descending_addresses():
+    """The block arrays of a vector may lie anywhere: the kernel's offset tables hold differences to block 0 that are
+    negative when a later block sits at a lower address (found by the slab driver: FGMRES stagnated on 12^3 cells)."""
+    from oracle import vanka_oracle
+    stfem = importlib.import_module("dealii-stfem_amd")
+    p, nc = 2, (3, 2, 3)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    ctx = stfem.MatrixFreeOperator(p, nc)
+    V = stfem.PreconditionVanka(ctx, Alpha, Beta)
+    ref = vanka_oracle.VankaOracle(p, nc, stfem.mesh_vertices(nc), 63, Alpha, Beta)
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-1, 1, (nb, ctx.n_dofs))
+    pool = stfem.BlockVector(ctx, 4)
+    ptrs = sorted(pool.block_ptr(b) for b in range(4))
+    for order in ((1, 0, 3, 2), (0, 1, 2, 3), (3, 2, 1, 0)):
+        src = stfem.BlockVector(ctx, device_ptrs=[ptrs[order[0]], ptrs[order[1]]])
+        dst = stfem.BlockVector(ctx, device_ptrs=[ptrs[order[2]], ptrs[order[3]]])
+        src.upload(X)
+        dst.upload(np.full((nb, ctx.n_dofs), 1e30))  # every entry must be overwritten
+        V.vmult(dst, src)
+        assert rel(dst.download(), ref.vmult(X)) < 1e-10, order
