@@ -9,7 +9,6 @@
 // Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
 #include "stfem/time_integrators.h"
 
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -76,14 +75,13 @@ int main(int argc, char **argv)
     }
     ErrorCalculator<Number> error_calculator(type, k, int(k + 1), K_mf.context(), exact, exact_grad); // exact_solution.h:524-526
 
-    double l2 = 0.0, l8 = -1.0, h1 = 0.0, time = 0.0, solve_s = 0.0;
+    double l2 = 0.0, l8 = -1.0, h1 = 0.0, time = 0.0, rhs_s = 0.0, solve_s = 0.0;
     unsigned total_its = 0, solves = 0;
     auto run = [&](auto &step) {
       while (time < end_time - 1e-12) {
-        const auto t0 = std::chrono::steady_clock::now();
         step.solve(x, prev_x, rhs, time, tau);
-        (void)dot(x, x); // synchronises
-        solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rhs_s = step.assemble_seconds;
+        solve_s = step.solver_seconds;
         total_its += step.last_step();
         ++solves;
         const auto e = error_calculator.evaluate_error(time, tau, x, prev_x, nsteps);
@@ -104,8 +102,8 @@ int main(int argc, char **argv)
       TimeIntegratorFO<Number, SystemN, SystemN, PreconditionIdentity> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps, true, 1e-12, max_steps);
       run(step);
     }
-    std::fprintf(stderr, "%u slab solves, %u FGMRES iterations, %.3f s in solve (rhs assembly + FGMRES): %.2f ms per iteration\n", solves,
-                 total_its, solve_s, 1e3 * solve_s / std::max(1u, total_its));
+    std::fprintf(stderr, "%u slab solves: right-hand sides %.3f s (source evaluated on the host), FGMRES %.3f s for %u iterations = %.2f ms per iteration\n",
+                 solves, rhs_s, solve_s, total_its, 1e3 * solve_s / std::max(1u, total_its));
     std::printf("%d %llu %u %.12e %.12e %.12e %.2f\n", n * n * n, (unsigned long long)K_mf.m(), x.n_blocks(), l8, std::sqrt(l2), std::sqrt(h1),
                 double(total_its) / solves);
   } catch (const std::exception &e) {

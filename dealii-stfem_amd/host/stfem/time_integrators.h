@@ -6,6 +6,7 @@
 #pragma once
 #include "operators.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -225,15 +226,22 @@ public:
   // solve (time_integrators.h:300-321); prev_x: one block
   void solve(V &x, const V &prev_x, V &rhs, double time, double time_step)
   {
+    const auto t0 = std::chrono::steady_clock::now();
     rhs_matrix.vmult_slice(rhs, prev_x);
     assemble_force(rhs, time, time_step);
+    (void)dot(rhs, rhs); // synchronises
+    const auto t1 = std::chrono::steady_clock::now();
     for (unsigned b = 0; b < x.n_blocks(); ++b) { // extrapolate (time_integrators.h:184-194)
       V view = block_view(x, b);
       axpby(do_extrapolate ? 1.0 : 0.0, prev_x, 0.0, view);
     }
     solver.solve(matrix, x, rhs, preconditioner);
+    (void)dot(x, x);
+    assemble_seconds += std::chrono::duration<double>(t1 - t0).count();
+    solver_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   }
   unsigned last_step() const { return solver.last_step(); }
+  double assemble_seconds = 0.0, solver_seconds = 0.0; // right-hand side (host evaluation of the source included) / FGMRES
 
 private:
   std::shared_ptr<Context> matrix_context() const
