@@ -31,6 +31,31 @@ template <typename Number> BlockVectorT<Number> block_view(const BlockVectorT<Nu
   return out;
 }
 
+// Blocks [first, first + count) of a block vector as a vector of their own (a view)
+template <typename Number> BlockVectorT<Number> block_range(const BlockVectorT<Number> &v, unsigned first, unsigned count)
+{
+  std::vector<void *> ptrs(count);
+  for (unsigned b = 0; b < count; ++b) ptrs[b] = stfem_vector_block(v.handle(), int(first + b));
+  BlockVectorT<Number> out;
+  out.wrap(v.context(), ptrs.data(), count);
+  return out;
+}
+// tensorproduct_add (include/operators.h:211-250): c[offset + i] += sum_j A(i, j) b[offset + j]  (b a block vector),
+// or += A(i, 0) b (b one spatial vector)
+template <typename Number>
+void tensorproduct_add(BlockVectorT<Number> &c, const FullMatrix<Number> &A, const BlockVectorT<Number> &b, unsigned block_offset = 0)
+{
+  std::vector<double> a(size_t(A.m()) * A.n());
+  for (size_t i = 0; i < a.size(); ++i) a[i] = double(A.data()[i]);
+  BlockVectorT<Number> cv = block_range(c, block_offset, A.m());
+  if (b.n_blocks() == 1 && A.n() == 1) {
+    check(stfem_tensorproduct_add(c.context()->h, int(A.m()), 1, a.data(), cv.handle(), b.handle(), nullptr), "stfem_tensorproduct_add");
+  } else {
+    BlockVectorT<Number> bv = block_range(b, block_offset, A.n());
+    check(stfem_tensorproduct_add(c.context()->h, int(A.m()), int(A.n()), a.data(), cv.handle(), bv.handle(), nullptr), "stfem_tensorproduct_add");
+  }
+}
+
 struct PreconditionIdentity {
   template <typename V> void vmult(V &dst, const V &src) const { axpby(1.0, src, 0.0, dst); }
 };
@@ -243,7 +268,7 @@ public:
   unsigned last_step() const { return solver.last_step(); }
   double assemble_seconds = 0.0, solver_seconds = 0.0; // right-hand side (host evaluation of the source included) / FGMRES
 
-private:
+protected:
   std::shared_ptr<Context> matrix_context() const
   {
     V probe;
@@ -263,6 +288,68 @@ private:
   bool do_extrapolate;
   int nq = 0;
   std::vector<double> qpoints;
+};
+
+// include/time_integrators.h:343-459: the wave equation as a first-order system with the velocity eliminated from the
+// slab system (fe_time.h:157-305 builds its temporal matrices); after the solve for u the velocity is recovered block
+// by block: v = A^-1 B u + A^-1 Gamma prev (dG: - A^-1 Gamma prev_u; cG: A^-1 Gamma prev_v - A^-1 Zeta prev_u).
+// Alpha .. Zeta are the ONE-step heat-type matrices (tests/tp_01.cc:123, 535-545).
+template <typename Number, typename System, typename RHSSystem, typename Preconditioner>
+class TimeIntegratorWave : public TimeIntegratorFO<Number, System, RHSSystem, Preconditioner> {
+  using Base = TimeIntegratorFO<Number, System, RHSSystem, Preconditioner>;
+
+public:
+  using V = BlockVectorT<Number>;
+  TimeIntegratorWave(TimeStepType type, unsigned time_degree, const FullMatrix<Number> &Alpha, const FullMatrix<Number> &Beta,
+                     const FullMatrix<Number> &Gamma, const FullMatrix<Number> &Zeta, double gmres_tolerance, const System &matrix,
+                     const Preconditioner &preconditioner, const RHSSystem &rhs_matrix, const RHSSystem &rhs_matrix_v,
+                     const PointFunction &source, unsigned n_timesteps_at_once, bool extrapolate = true, unsigned max_steps = 200)
+    : Base(type, time_degree, Alpha, Gamma, gmres_tolerance, matrix, preconditioner, rhs_matrix, source, n_timesteps_at_once, extrapolate, 1e-12,
+           max_steps),
+      rhs_matrix_v(rhs_matrix_v), Alpha_inv(Alpha)
+  {
+    Alpha_inv.gauss_jordan();
+    Alpha_inv.mmult(AixB, Beta);
+    Alpha_inv.mmult(AixG, Gamma);
+    Alpha_inv.mmult(AixZ, Zeta);
+    if (type == TimeStepType::DG) AixG *= Number(-1);
+    else AixZ *= Number(-1);
+  }
+
+  // prev_u, prev_v: one block each
+  void solve(V &u, V &v, V &rhs, const V &prev_u, const V &prev_v, double time, double time_step)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    this->rhs_matrix.vmult_slice(rhs, prev_u);
+    for (unsigned b = 0; b < u.n_blocks(); ++b) {
+      V view = block_view(u, b);
+      axpby(this->do_extrapolate ? 1.0 : 0.0, prev_u, 0.0, view);
+    }
+    rhs_matrix_v.vmult_slice_add(rhs, prev_v);
+    this->assemble_force(rhs, time, time_step);
+    (void)dot(rhs, rhs);
+    const auto t1 = std::chrono::steady_clock::now();
+    this->solver.solve(this->matrix, u, rhs, this->preconditioner);
+    const unsigned nt_dofs = AixB.m();
+    axpby(0.0, v, 0.0, v);
+    for (unsigned it = 0; it < this->n_timesteps_at_once; ++it) {
+      const V pu = it == 0 ? block_view(prev_u, 0) : block_view(u, it * nt_dofs - 1);
+      tensorproduct_add(v, AixB, u, it * nt_dofs);
+      if (this->type == TimeStepType::DG) tensorproduct_add(v, AixG, pu, it * nt_dofs);
+      else {
+        const V pv = it == 0 ? block_view(prev_v, 0) : block_view(v, it * nt_dofs - 1);
+        tensorproduct_add(v, AixG, pv, it * nt_dofs);
+        tensorproduct_add(v, AixZ, pu, it * nt_dofs);
+      }
+    }
+    (void)dot(v, v);
+    this->assemble_seconds += std::chrono::duration<double>(t1 - t0).count();
+    this->solver_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+  }
+
+private:
+  const RHSSystem &rhs_matrix_v;
+  FullMatrix<Number> Alpha_inv, AixB, AixG, AixZ;
 };
 
 // include/exact_solution.h:503-649: errors of the space-time solution on one slab, QGauss(time degree + 1) in time

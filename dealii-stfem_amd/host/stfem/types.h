@@ -7,6 +7,7 @@
 #include "../../../include/stfem.h"
 
 #include <array>
+#include <cmath>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -41,6 +42,51 @@ public:
   }
   const Number *data() const { return v_.data(); }
   Number *data() { return v_.data(); }
+  // C = this * B
+  void mmult(FullMatrix &C, const FullMatrix &B) const
+  {
+    C = FullMatrix(m_, B.n_);
+    for (unsigned i = 0; i < m_; ++i)
+      for (unsigned k = 0; k < n_; ++k)
+        for (unsigned j = 0; j < B.n_; ++j) C(i, j) += (*this)(i, k) * B(k, j);
+  }
+  FullMatrix &operator*=(Number s)
+  {
+    for (Number &x : v_) x *= s;
+    return *this;
+  }
+  // in-place inverse (dealii::FullMatrix::gauss_jordan), partial pivoting
+  void gauss_jordan()
+  {
+    if (m_ != n_) throw std::invalid_argument("gauss_jordan: square matrices only");
+    const unsigned n = n_;
+    std::vector<double> A(v_.begin(), v_.end()), I(size_t(n) * n, 0.0);
+    for (unsigned i = 0; i < n; ++i) I[size_t(i) * n + i] = 1.0;
+    for (unsigned c = 0; c < n; ++c) {
+      unsigned p = c;
+      for (unsigned r = c + 1; r < n; ++r)
+        if (std::abs(A[size_t(r) * n + c]) > std::abs(A[size_t(p) * n + c])) p = r;
+      if (A[size_t(p) * n + c] == 0.0) throw std::runtime_error("gauss_jordan: singular matrix");
+      for (unsigned k = 0; k < n; ++k) {
+        std::swap(A[size_t(c) * n + k], A[size_t(p) * n + k]);
+        std::swap(I[size_t(c) * n + k], I[size_t(p) * n + k]);
+      }
+      const double inv = 1.0 / A[size_t(c) * n + c];
+      for (unsigned k = 0; k < n; ++k) {
+        A[size_t(c) * n + k] *= inv;
+        I[size_t(c) * n + k] *= inv;
+      }
+      for (unsigned r = 0; r < n; ++r) {
+        if (r == c) continue;
+        const double f = A[size_t(r) * n + c];
+        for (unsigned k = 0; k < n; ++k) {
+          A[size_t(r) * n + k] -= f * A[size_t(c) * n + k];
+          I[size_t(r) * n + k] -= f * I[size_t(c) * n + k];
+        }
+      }
+    }
+    for (size_t i = 0; i < v_.size(); ++i) v_[i] = Number(I[i]);
+  }
   template <typename N2> FullMatrix<N2> cast() const
   {
     FullMatrix<N2> r(m_, n_);

@@ -1,0 +1,121 @@
+// The reference's space-time convergence test of the WAVE equation (tests/tp_01.cc with space_time_conv_test,
+// ProblemType::wave: u_tt - laplace u = f, include/time_integrators.h:343-459, include/exact_solution.h:147-197)
+// in 3D on the device: u = sin(2 pi f t) prod sin(2 pi f x_d), v = u_t, on the unit cube, FE_Q(k + 1) in
+// space, dG(k) / cG(k) in time, tau = 2^-(refinement + 1), n_timesteps_at_once steps per solve, FGMRES
+// (200 steps, restart 100, 1e-12) preconditioned by relaxation sweeps of the cell-patch Vanka smoother
+// (the reference preconditions with its space-time multigrid, SURVEY 8 f-2, not built: the errors do not depend
+// on the preconditioner, the iteration counts do).
+// Usage: wave_convergence <type 0 = cG | 1 = dG> <k> <refinement> <n_timesteps_at_once> [vanka sweeps = 2, 0 = none] [omega = 0.5]
+//                         [fe_degree = k + 1] [cells per direction = 2^refinement] [end_time = 1] [FGMRES steps = 200]
+// Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
+#include "stfem/time_integrators.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+using namespace stfem;
+using Number = double;
+
+int main(int argc, char **argv)
+{
+  if (argc < 5) {
+    std::fprintf(stderr, "usage: %s type k refinement n_timesteps_at_once [sweeps] [omega]\n", argv[0]);
+    return 2;
+  }
+  const auto type = std::atoi(argv[1]) == 0 ? TimeStepType::CGP : TimeStepType::DG;
+  const unsigned k = std::atoi(argv[2]), refinement = std::atoi(argv[3]), nsteps = std::atoi(argv[4]);
+  const unsigned sweeps = argc > 5 ? std::atoi(argv[5]) : 2;
+  const double omega = argc > 6 ? std::atof(argv[6]) : 0.5;
+  const unsigned fe_degree = argc > 7 ? std::atoi(argv[7]) : k + 1; // tests/tp_01.cc:76
+  const int n = argc > 8 ? std::atoi(argv[8]) : 1 << refinement;    // subdivided_hyper_rectangle with one subdivision, refined globally
+  const double tau = std::ldexp(1.0, -int(refinement + 1)), end_time = argc > 9 ? std::atof(argv[9]) : 1.0, f = 1.0, PI = 3.14159265358979323846;
+  const unsigned max_steps = argc > 10 ? std::atoi(argv[10]) : 200;
+  try {
+    Mesh mesh;
+    mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = n;
+    MatrixFreeOperatorScalar<3, Number> K_mf(mesh, fe_degree, 0.0, 1.0), M_mf(K_mf, 1.0, 0.0);
+    auto [Alpha_1, Beta_1, Gamma_1, Zeta_1] = get_fe_time_weights<Number>(type, k, tau, 1);
+    // tests/tp_01.cc:143-158: slab matrices of the second-order system with the velocity eliminated
+    auto [Alpha, Beta, rhs_uK, rhs_uM, rhs_vM] = get_fe_time_weights_wave<Number>(type, k, tau, nsteps);
+    using SystemN = SystemMatrix<3, Number, MatrixFreeOperatorScalar<3, Number>>;
+    SystemN matrix(K_mf, M_mf, Alpha, Beta);
+    FullMatrix<Number> zero(rhs_vM.m(), 1);
+    SystemN rhs_matrix(K_mf, M_mf, rhs_uK, rhs_uM), rhs_matrix_v(K_mf, M_mf, zero, rhs_vM);
+
+    auto product = [&](double amp, const std::vector<double> &pts, std::vector<double> &out) {
+      out.resize(pts.size() / 3);
+      for (size_t i = 0; i < out.size(); ++i)
+        out[i] = amp * std::sin(2 * PI * f * pts[3 * i]) * std::sin(2 * PI * f * pts[3 * i + 1]) * std::sin(2 * PI * f * pts[3 * i + 2]);
+    };
+    // include/exact_solution.h:27-81
+    PointFunction exact = [&](double t, const std::vector<double> &pts, std::vector<double> &out) { product(std::sin(2 * PI * f * t), pts, out); };
+    PointFunction source = [&](double t, const std::vector<double> &pts, std::vector<double> &out) {
+      product(8 * PI * PI * f * f * std::sin(2 * PI * f * t), pts, out); // pow(2, dim) (pi f)^2 sin(2 pi f t)
+    };
+    PointFunction exact_grad = [&](double t, const std::vector<double> &pts, std::vector<double> &out) {
+      out.resize(pts.size());
+      const double tv = 2 * PI * f * std::sin(2 * PI * f * t);
+      for (size_t i = 0; i < pts.size() / 3; ++i)
+        for (int d = 0; d < 3; ++d) {
+          double g = tv;
+          for (int e = 0; e < 3; ++e) g *= d == e ? std::cos(2 * PI * f * pts[3 * i + e]) : std::sin(2 * PI * f * pts[3 * i + e]);
+          out[3 * i + d] = g;
+        }
+    };
+
+    BlockVectorT<Number> x, v, rhs, prev_x, prev_v;
+    matrix.initialize_dof_vector(x);
+    matrix.initialize_dof_vector(v);
+    matrix.initialize_dof_vector(rhs);
+    prev_x.reinit(K_mf.context(), 1);
+    prev_v.reinit(K_mf.context(), 1);
+    { // VectorTools::interpolate of u and v = u_t at t = 0 (constrained nodes: the functions vanish there)
+      std::vector<double> pts(3 * prev_x.block_size()), u0, v0;
+      check(stfem_support_points(K_mf.context()->h, pts.data()), "stfem_support_points");
+      exact(0.0, pts, u0);
+      product(2 * PI * f, pts, v0); // wave::ExactSolutionV at t = 0
+      prev_x.copy_from_host({u0});
+      prev_v.copy_from_host({v0});
+    }
+    ErrorCalculator<Number> error_calculator(type, k, int(k + 1), K_mf.context(), exact, exact_grad); // exact_solution.h:524-526
+
+    double l2 = 0.0, l8 = -1.0, h1 = 0.0, time = 0.0, rhs_s = 0.0, solve_s = 0.0;
+    unsigned total_its = 0, solves = 0;
+    auto run = [&](auto &step) {
+      while (time < end_time - 1e-12) {
+        step.solve(x, v, rhs, prev_x, prev_v, time, tau);
+        rhs_s = step.assemble_seconds;
+        solve_s = step.solver_seconds;
+        total_its += step.last_step();
+        ++solves;
+        const auto e = error_calculator.evaluate_error(time, tau, x, prev_x, nsteps);
+        l2 += e[0];
+        l8 = std::max(l8, e[1]);
+        h1 += e[2];
+        axpby(1.0, block_view(x, x.n_blocks() - 1), 0.0, prev_x);
+        axpby(1.0, block_view(v, v.n_blocks() - 1), 0.0, prev_v);
+        time += nsteps * tau;
+      }
+    };
+    if (sweeps > 0) {
+      PreconditionVanka<Number> vanka(K_mf, Alpha, Beta);
+      PreconditionRelaxation<Number, SystemN> precond(matrix, vanka, omega, sweeps);
+      TimeIntegratorWave<Number, SystemN, SystemN, decltype(precond)> step(type, k, Alpha_1, Beta_1, Gamma_1, Zeta_1, 1e-12, matrix, precond, rhs_matrix,
+                                                                           rhs_matrix_v, source, nsteps, true, max_steps);
+      run(step);
+    } else {
+      PreconditionIdentity precond;
+      TimeIntegratorWave<Number, SystemN, SystemN, PreconditionIdentity> step(type, k, Alpha_1, Beta_1, Gamma_1, Zeta_1, 1e-12, matrix, precond, rhs_matrix,
+                                                                              rhs_matrix_v, source, nsteps, true, max_steps);
+      run(step);
+    }
+    std::fprintf(stderr, "%u slab solves: right-hand sides %.3f s (source evaluated on the host), FGMRES %.3f s for %u iterations = %.2f ms per iteration\n",
+                 solves, rhs_s, solve_s, total_its, 1e3 * solve_s / std::max(1u, total_its));
+    std::printf("%d %llu %u %.12e %.12e %.12e %.2f\n", n * n * n, (unsigned long long)K_mf.m(), x.n_blocks(), l8, std::sqrt(l2), std::sqrt(h1),
+                double(total_its) / solves);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -48,7 +48,13 @@ def matrices_1d(p, n):
     return M, K
 
 
-def heat_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0):
+def wave_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0):
+    """The same for the wave equation u_tt - laplace u = f (tests/tp_01.cc ProblemType::wave, include/time_integrators.h:343-459,
+    include/exact_solution.h:147-197): slab system of fe_time.h:157-305 for u, velocity recovered block by block."""
+    return heat_convergence_row_3d(ttype, k, refinement, nsteps, frequency, wave=True)
+
+
+def heat_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0, wave=False):
     """(L-inf L-inf, L2 L2, L2 H1-semi) of u = sin(2 pi f t) prod_d sin(2 pi f x_d) on the unit cube,
     FE_Q(k + 1) x {cG, dG}(k), 2^refinement cells per direction, tau = 2^-(refinement + 1)"""
     p = k + 1
@@ -62,19 +68,28 @@ def heat_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0):
     M = np.kron(Mi, np.kron(Mi, Mi))
     K = np.kron(Ki, np.kron(Mi, Mi)) + np.kron(Mi, np.kron(Ki, Mi)) + np.kron(Mi, np.kron(Mi, Ki))
     nfree = (nd - 2) ** 3
-    A, B, G, Z = o.time_weights(ttype, k, tau, nsteps)
-    A1, _, G1, _ = o.time_weights(ttype, k, tau, 1)
+    A1, B1, G1, Z1 = o.time_weights(ttype, k, tau, 1)
     ntd = k if ttype == o.CGP else k + 1
     nb = ntd * nsteps
+    if wave:  # tests/tp_01.cc:143-158
+        A, B, rK, rM, rV = o.time_weights_wave(ttype, k, tau, nsteps)
+        Ainv = np.linalg.inv(A1)
+        AixB, AixG, AixZ = Ainv @ B1, Ainv @ G1, Ainv @ Z1
+        if ttype == o.DG:
+            AixG = -AixG
+        else:
+            AixZ = -AixZ
+    else:
+        A, B, G, Z = o.time_weights(ttype, k, tau, nsteps)
+        rK, rM = (G, Z) if ttype == o.CGP else (np.zeros_like(G), G)
     sysmat = np.kron(A, K) + np.kron(B, M)
-    rK, rM = (G, Z) if ttype == o.CGP else (np.zeros_like(G), G)
     gll = o.gauss_lobatto(p + 1)
     xq, wq = o.gauss(p + 1)
     S, _ = o.shape_tables(p)
     w2 = 2 * np.pi * frequency
 
     def load_vector(t):
-        amp = 3 * (w2 ** 2) * np.sin(w2 * t) + w2 * np.cos(w2 * t)
+        amp = (2 * w2 ** 2 * np.sin(w2 * t)) if wave else (3 * (w2 ** 2) * np.sin(w2 * t) + w2 * np.cos(w2 * t))
         f = np.zeros(nd)
         for c in range(n):
             xs = h * (c + xq)
@@ -115,12 +130,17 @@ def heat_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0):
         return l2, l8, h1
 
     prev = np.zeros(nfree)
+    # v(0) = 2 pi f prod sin(2 pi f x_d) interpolated at the nodes
+    xn = np.concatenate([h * (c + gll[:-1]) for c in range(n)] + [[1.0]])[f1]
+    prev_v = w2 * np.einsum("i,j,k->ijk", np.sin(w2 * xn), np.sin(w2 * xn), np.sin(w2 * xn)).ravel()
     time, acc_l2, acc_l8, acc_h1 = 0.0, 0.0, -1.0, 0.0
     while time < 1.0 - 1e-12:
         rhs = np.zeros(nb * nfree)
         blk = lambda j: slice(j * nfree, (j + 1) * nfree)  # noqa: E731
         for j in range(nb):
             rhs[blk(j)] = rK[j, 0] * (K @ prev) + rM[j, 0] * (M @ prev)
+            if wave:
+                rhs[blk(j)] += rV[j, 0] * (M @ prev_v)
         for it in range(nsteps):
             for j, xi in enumerate(tq_int):
                 F = load_vector(time + tau * it + tau * xi)
@@ -143,6 +163,18 @@ def heat_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0):
                 acc_l2 += tau * ewt[q] * l2
                 acc_h1 += tau * ewt[q] * h1
                 acc_l8 = max(acc_l8, l8)
+        if wave:  # velocity recovery (time_integrators.h:429-446)
+            v = np.zeros_like(x)
+            for it in range(nsteps):
+                sl = slice(it * ntd, (it + 1) * ntd)
+                pu = prev if it == 0 else x[it * ntd - 1]
+                v[sl] = AixB @ x[sl]
+                if ttype == o.DG:
+                    v[sl] += AixG @ pu[None, :]
+                else:
+                    pv = prev_v if it == 0 else v[it * ntd - 1]
+                    v[sl] += AixG @ pv[None, :] + AixZ @ pu[None, :]
+            prev_v = v[-1]
         prev = x[-1]
         time += nsteps * tau
     return acc_l8, np.sqrt(acc_l2), np.sqrt(acc_h1)

@@ -1,4 +1,4 @@
-"""Slab driver: the reference's heat convergence test (tests/tp_01.cc, space_time_conv_test) in 3D on
+"""Slab driver: the reference's heat and wave convergence tests (tests/tp_01.cc, space_time_conv_test) in 3D on
 the device - C++ caller host/heat_convergence.cpp on host/stfem/time_integrators.h: load vectors, vmult_slice right-hand
 side, FGMRES preconditioned by Vanka relaxation sweeps, error norms - against the dense direct-solve restatement
 oracle/slab_oracle.py (the recipe tests/test_tp01_reference.py pins to the reference's own 2D numbers)."""
@@ -34,3 +34,24 @@ def test_heat_convergence_row(ttype, k, refinement, nsteps, sweeps):
     # the slab systems are solved to 1e-12 (relative): the error norms agree far below their own size
     assert np.allclose(got, np.array(want), rtol=1e-7, atol=1e-10), (got, want)
     assert float(its) <= 200
+
+
+@pytest.mark.parametrize("ttype,k,refinement,nsteps,sweeps", [
+    (0, 1, 1, 2, 2),   # cG(1), Q2
+    (0, 1, 2, 2, 2),
+    (1, 1, 1, 2, 2),   # dG(1)
+    (0, 2, 1, 1, 1),   # cG(2), Q3
+])
+def test_wave_convergence_row(ttype, k, refinement, nsteps, sweeps):
+    """TimeIntegratorWave (time_integrators.h:343-459): slab solve for u with the wave matrices of fe_time.h:157-305,
+    right-hand side from prev_u and prev_v, velocity recovery by tensorproduct_add."""
+    from oracle import slab_oracle
+    exe = os.path.join(HOST, "wave_convergence")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    res = subprocess.run([exe, str(ttype), str(k), str(refinement), str(nsteps), str(sweeps)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    cells, sdofs, tdofs, l8, l2, h1, its = res.stdout.split()
+    want = slab_oracle.wave_convergence_row_3d(ttype, k, refinement, nsteps)
+    got = np.array([float(l8), float(l2), float(h1)])
+    assert np.allclose(got, np.array(want), rtol=1e-7, atol=1e-10), (got, want)
