@@ -99,6 +99,9 @@ SIGNATURES = {
     "stfem_driver_last_error": (C.c_char_p, []),
     "stfem_gauss_rule": (C.c_int, [C.c_int, _dp, _dp]),
     "stfem_fe_time_points": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "stfem_time_prolongation_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "stfem_time_restriction_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "stfem_time_projection_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
     "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
     "stfem_vanka_destroy": (None, [_vp]),
     "stfem_vanka_n_classes": (C.c_int, [_vp]),
@@ -160,6 +163,29 @@ def _check(status, what):
 
 
 # --------------------------------------------------------------------------- host helpers
+
+
+def _time_transfer(fn, *args):
+    dims = (C.c_int32 * 2)()
+    _check(fn(*args, None, dims), fn.__name__)
+    out = np.zeros((dims[0], dims[1]))
+    _check(fn(*args, _p(out), dims), fn.__name__)
+    return out
+
+
+def get_time_prolongation_matrix(ttype, r, n_timesteps_at_once=2):
+    """fe_time.h:805-849"""
+    return _time_transfer(lib().stfem_time_prolongation_matrix, ttype, r, n_timesteps_at_once)
+
+
+def get_time_restriction_matrix(ttype, r, n_timesteps_at_once=2):
+    """fe_time.h:851-898"""
+    return _time_transfer(lib().stfem_time_restriction_matrix, ttype, r, n_timesteps_at_once)
+
+
+def get_time_projection_matrix(ttype, r_src, r_dst, n_timesteps_at_once=1):
+    """fe_time.h:749-803"""
+    return _time_transfer(lib().stfem_time_projection_matrix, ttype, r_src, r_dst, n_timesteps_at_once)
 
 
 def get_fe_time_weights(ttype, r, time_step_size=1.0, n_timesteps_at_once=1):

@@ -509,6 +509,125 @@ Mat inverse(int n, Mat A)
 
 } // namespace
 
+// ---- time-multigrid transfer matrices (reference include/fe_time.h:749-898) ----
+// The deal.II pieces the reference calls, spelled out for the 1D Lagrange elements on the Gauss-Lobatto (cG) /
+// right Gauss-Radau (dG) points: get_prolongation_matrix(child) = the parent basis at the child's support points;
+// FE_Q::get_restriction_matrix(child) = the child basis at the parent's support points lying in that child;
+// FE_DGQArbitraryNodes::get_restriction_matrix and FETools::get_projection_matrix = L2 projections.
+namespace {
+std::vector<double> time_nodes(int type, int r) { return type == 0 ? lobatto_points(r + 1) : radau_right_points(r + 1); }
+Mat lagrange_at(const std::vector<double> &nodes, const std::vector<double> &x)
+{
+  Mat V, G;
+  lagrange_tables(nodes, x, V, G);
+  return V; // [x][node]
+}
+Mat mass_like(const std::vector<double> &rows, const std::vector<double> &cols, int nq)
+{
+  std::vector<double> xq, wq;
+  gauss_rule(nq, xq, wq);
+  const Mat Vr = lagrange_at(rows, xq), Vc = lagrange_at(cols, xq);
+  const int nr = int(rows.size()), nc = int(cols.size());
+  Mat M(size_t(nr) * nc, 0.0);
+  for (int q = 0; q < nq; ++q)
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nc; ++j) M[i * nc + j] += wq[q] * Vr[q * nr + i] * Vc[q * nc + j];
+  return M;
+}
+} // namespace
+
+int time_prolongation(int type, int r, int nsteps, Mat &out, int &m, int &n)
+{
+  if ((type != 0 && type != 1) || r < (type == 0 ? 1 : 0) || r > 8 || nsteps < 2 || (nsteps & (nsteps - 1))) return -1;
+  const std::vector<double> x = time_nodes(type, r);
+  const int np = r + 1, skip = type == 0 ? 1 : 0, nd = np - skip; // cG: the left end belongs to the previous step
+  std::vector<double> xl(np), xr(np);
+  for (int i = 0; i < np; ++i) { xl[i] = x[i] / 2; xr[i] = (x[i] + 1) / 2; }
+  const Mat L = lagrange_at(x, xl), R = lagrange_at(x, xr);
+  m = nd * nsteps; n = nd * nsteps / 2;
+  out.assign(size_t(m) * n, 0.0);
+  for (int it = 0; it < nsteps / 2; ++it)
+    for (int i = 0; i < nd; ++i)
+      for (int j = 0; j < nd; ++j) {
+        out[size_t(2 * nd * it + i) * n + nd * it + j] = L[(i + skip) * np + j + skip];
+        out[size_t(2 * nd * it + nd + i) * n + nd * it + j] = R[(i + skip) * np + j + skip];
+      }
+  return 0;
+}
+
+int time_restriction(int type, int r, int nsteps, Mat &out, int &m, int &n)
+{
+  if ((type != 0 && type != 1) || r < (type == 0 ? 1 : 0) || r > 8 || nsteps < 2 || (nsteps & (nsteps - 1))) return -1;
+  const std::vector<double> x = time_nodes(type, r);
+  const int np = r + 1, skip = type == 0 ? 1 : 0, nd = np - skip;
+  Mat Rl(size_t(np) * np, 0.0), Rr(size_t(np) * np, 0.0);
+  if (type == 0) {
+    const double eps = 1e-12;
+    for (int i = 0; i < np; ++i) {
+      if (x[i] <= 0.5 + eps) {
+        const Mat v = lagrange_at(x, {std::min(1.0, 2 * x[i])});
+        for (int j = 0; j < np; ++j) Rl[i * np + j] = v[j];
+      }
+      if (x[i] >= 0.5 - eps) {
+        const Mat v = lagrange_at(x, {std::max(0.0, 2 * x[i] - 1)});
+        for (int j = 0; j < np; ++j) Rr[i * np + j] = v[j];
+      }
+    }
+  } else {
+    std::vector<double> xl(np), xr(np);
+    for (int i = 0; i < np; ++i) { xl[i] = x[i] / 2; xr[i] = (x[i] + 1) / 2; }
+    const Mat Pl = lagrange_at(x, xl), Pr = lagrange_at(x, xr), M = mass_like(x, x, r + 2), Mi = inverse(np, M);
+    auto half_projection = [&](const Mat &P) { // M^-1 P^T M / 2
+      Mat PT(size_t(np) * np);
+      for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) PT[i * np + j] = P[j * np + i];
+      Mat A = matmul(np, np, np, Mi, matmul(np, np, np, PT, M));
+      for (double &v : A) v *= 0.5;
+      return A;
+    };
+    Rl = half_projection(Pl);
+    Rr = half_projection(Pr);
+  }
+  m = nd * nsteps / 2; n = nd * nsteps;
+  out.assign(size_t(m) * n, 0.0);
+  for (int it = 0; it < nsteps / 2; ++it)
+    for (int i = 0; i < nd; ++i)
+      for (int j = 0; j < nd; ++j) {
+        out[size_t(nd * it + i) * n + 2 * nd * it + j] = Rl[(i + skip) * np + j + skip];
+        out[size_t(nd * it + i) * n + 2 * nd * it + nd + j] = Rr[(i + skip) * np + j + skip];
+      }
+  return 0;
+}
+
+int time_projection(int type, int r_src, int r_dst, int nsteps, Mat &out, int &m, int &n)
+{
+  const int rmin = type == 0 ? 1 : 0;
+  if ((type != 0 && type != 1) || r_src < rmin || r_dst < rmin || r_src > 8 || r_dst > 8 || nsteps < 1) return -1;
+  const std::vector<double> xs = time_nodes(type, r_src), xd = time_nodes(type, r_dst);
+  const int ns = r_src + 1, nd = r_dst + 1, nq = std::max(r_src, r_dst) + 2;
+  const Mat P = matmul(nd, nd, ns, inverse(nd, mass_like(xd, xd, nq)), mass_like(xd, xs, nq)); // [dst][src]
+  if (type == 1) {
+    m = nsteps * nd; n = nsteps * ns;
+    out.assign(size_t(m) * n, 0.0);
+    for (int it = 0; it < nsteps; ++it)
+      for (int i = 0; i < nd; ++i)
+        for (int j = 0; j < ns; ++j) out[size_t(it * nd + i) * n + it * ns + j] = P[i * ns + j];
+    return 0;
+  }
+  // cG: consecutive steps share their end point (a later step's block overwrites the shared entry), then the
+  // first row and column - the dof at the start of the slab - are dropped
+  const int fm = nsteps * r_dst + 1, fn = nsteps * r_src + 1;
+  Mat full(size_t(fm) * fn, 0.0);
+  for (int it = 0; it < nsteps; ++it)
+    for (int i = 0; i < nd; ++i)
+      for (int j = 0; j < ns; ++j) full[size_t(it * r_dst + i) * fn + it * r_src + j] = P[i * ns + j];
+  m = fm - 1; n = fn - 1;
+  out.assign(size_t(m) * n, 0.0);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j) out[size_t(i) * n + j] = full[size_t(i + 1) * fn + j + 1];
+  return 0;
+}
+
 int fe_time_weights(int type, int r, double tau, int nsteps, Mat &Alpha, Mat &Beta, Mat &Gamma,
                     Mat &Zeta)
 {

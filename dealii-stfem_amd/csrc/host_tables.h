@@ -52,6 +52,11 @@ int fe_time_weights(int type, int r, double tau, int nsteps, Mat &Alpha, Mat &Be
 int fe_time_weights_wave(int type, int r, double tau, int nsteps, Mat &A_lhs, Mat &B_lhs,
                          Mat &rhs_uK, Mat &rhs_uM, Mat &rhs_vM);
 
+// time-multigrid transfer matrices (fe_time.h:749-898), row-major m x n; return 0 or -1 (bad arguments)
+int time_prolongation(int type, int r, int nsteps, Mat &out, int &m, int &n);
+int time_restriction(int type, int r, int nsteps, Mat &out, int &m, int &n);
+int time_projection(int type, int r_src, int r_dst, int nsteps, Mat &out, int &m, int &n);
+
 // ---- mesh / coefficient ----
 void mesh_vertices(const int32_t gn[3], const double lo[3], const double up[3], double distort,
                    uint64_t seed, int32_t z0, int32_t z1, double *out);

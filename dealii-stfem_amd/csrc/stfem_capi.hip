@@ -1002,6 +1002,37 @@ int stfem_plane_unpack(stfem_ctx *c, stfem_vec *v, int iz, const void *buf, int 
 
 // ------------------------------------------------------------------------------------ host helpers
 
+// time-multigrid transfer matrices (fe_time.h:749-898); out may be NULL to ask for the dimensions only
+static int time_transfer_out(int rc, const Mat &M, int m, int n, double *out, int32_t dims[2])
+{
+  if (rc != 0 || !dims) return STFEM_ERR_INVALID_ARGUMENT;
+  dims[0] = m;
+  dims[1] = n;
+  if (out) std::copy(M.begin(), M.end(), out);
+  return STFEM_OK;
+}
+int stfem_time_prolongation_matrix(int type, int r, int n_timesteps_at_once, double *out, int32_t dims[2])
+{
+  Mat M;
+  int m = 0, n = 0;
+  const int rc = time_prolongation(type, r, n_timesteps_at_once, M, m, n);
+  return time_transfer_out(rc, M, m, n, out, dims);
+}
+int stfem_time_restriction_matrix(int type, int r, int n_timesteps_at_once, double *out, int32_t dims[2])
+{
+  Mat M;
+  int m = 0, n = 0;
+  const int rc = time_restriction(type, r, n_timesteps_at_once, M, m, n);
+  return time_transfer_out(rc, M, m, n, out, dims);
+}
+int stfem_time_projection_matrix(int type, int r_src, int r_dst, int n_timesteps_at_once, double *out, int32_t dims[2])
+{
+  Mat M;
+  int m = 0, n = 0;
+  const int rc = time_projection(type, r_src, r_dst, n_timesteps_at_once, M, m, n);
+  return time_transfer_out(rc, M, m, n, out, dims);
+}
+
 int stfem_fe_time_weights(int type, int r, double tau, int ns, double *Alpha, double *Beta,
                           double *Gamma, double *Zeta)
 {

@@ -41,4 +41,28 @@ std::array<FullMatrix<Number>, 5> get_fe_time_weights_wave(TimeStepType type, un
   return w;
 }
 
+// fe_time.h:749-898: time-multigrid transfer matrices
+template <typename Number = double, typename F, typename... A> FullMatrix<Number> time_transfer_matrix(F fn, const char *what, A... args)
+{
+  int32_t dims[2];
+  if (fn(args..., nullptr, dims) != STFEM_OK) throw Error(STFEM_ERR_INVALID_ARGUMENT, what);
+  FullMatrix<double> d{unsigned(dims[0]), unsigned(dims[1])};
+  if (fn(args..., d.data(), dims) != STFEM_OK) throw Error(STFEM_ERR_INVALID_ARGUMENT, what);
+  return d.template cast<Number>();
+}
+template <typename Number = double> FullMatrix<Number> get_time_prolongation_matrix(TimeStepType type, unsigned r, unsigned n_timesteps_at_once = 2)
+{
+  return time_transfer_matrix<Number>(stfem_time_prolongation_matrix, "get_time_prolongation_matrix", int(type), int(r), int(n_timesteps_at_once));
+}
+template <typename Number = double> FullMatrix<Number> get_time_restriction_matrix(TimeStepType type, unsigned r, unsigned n_timesteps_at_once = 2)
+{
+  return time_transfer_matrix<Number>(stfem_time_restriction_matrix, "get_time_restriction_matrix", int(type), int(r), int(n_timesteps_at_once));
+}
+template <typename Number = double>
+FullMatrix<Number> get_time_projection_matrix(TimeStepType type, unsigned r_src, unsigned r_dst, unsigned n_timesteps_at_once)
+{
+  return time_transfer_matrix<Number>(stfem_time_projection_matrix, "get_time_projection_matrix", int(type), int(r_src), int(r_dst),
+                                      int(n_timesteps_at_once));
+}
+
 } // namespace stfem

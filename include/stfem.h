@@ -189,6 +189,15 @@ int stfem_halo_end(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, void *stream)
 int stfem_dot_global(stfem_ctx *ctx, stfem_comm *comm, const stfem_vec *a, const stfem_vec *b,
                      int64_t n_own, double *out, void *stream);
 
+/* Time-multigrid transfer matrices (include/fe_time.h:749-898: get_time_prolongation_matrix,
+ * get_time_restriction_matrix, get_time_projection_matrix), row-major dims[0] x dims[1]; `out` may be NULL to ask
+ * for the dimensions only.  type: 0 = cG, 1 = dG.  Prolongation / restriction couple n_timesteps_at_once fine steps
+ * with half as many of twice the length (a power of two >= 2); the projection changes the temporal degree.  They act
+ * on block vectors through stfem_tensorproduct_add (the reference: tensorproduct_add in MGTwoLevelTransferTime). */
+int stfem_time_prolongation_matrix(int type, int r, int n_timesteps_at_once, double *out, int32_t dims[2]);
+int stfem_time_restriction_matrix(int type, int r, int n_timesteps_at_once, double *out, int32_t dims[2]);
+int stfem_time_projection_matrix(int type, int r_src, int r_dst, int n_timesteps_at_once, double *out, int32_t dims[2]);
+
 /* Cell-patch Vanka / additive-Schwarz smoother of the space-time system A = Alpha (x) K + Beta (x) M:
  * PreconditionVanka (include/stmg.h:619-907; set-up 786-829 with compute_block_matrix.h:50-139, apply
  * 832-872).  create: builds and inverts the valence-weighted cell blocks of the ASSEMBLED matrices (zero

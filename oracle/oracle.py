@@ -294,3 +294,78 @@ class CpuBaseline:
                                  src, dst, _p(self._tmp), self.threads)
         assert rc == 0
         return Y
+
+
+# ---- time-multigrid transfer matrices (reference include/fe_time.h:749-898): restated with the deal.II pieces they
+# call spelled out - FiniteElement::get_prolongation_matrix / get_restriction_matrix of the 1D Lagrange elements on
+# the Gauss-Lobatto (cG) / right Gauss-Radau (dG) points, and FETools::get_projection_matrix (L2 projection on the
+# reference cell).  Pinned by the reference's tests/transfer_02.output (tests/test_time_transfers.py).
+def _lagrange(nodes, x):
+    nodes = np.asarray(nodes, float)
+    x = np.atleast_1d(np.asarray(x, float))
+    L = np.ones((len(x), len(nodes)))
+    for a in range(len(nodes)):
+        for m in range(len(nodes)):
+            if m != a:
+                L[:, a] *= (x - nodes[m]) / (nodes[a] - nodes[m])
+    return L
+
+
+def _time_nodes(ttype, r):
+    return np.asarray(gauss_lobatto(r + 1) if ttype == CGP else gauss_radau_right(r + 1), float)
+
+
+def time_prolongation(ttype, r, nsteps=2):
+    """get_time_prolongation_matrix (fe_time.h:805-849): two fine time steps <- one coarse step of twice the length"""
+    x = _time_nodes(ttype, r)
+    left, right = _lagrange(x, x / 2), _lagrange(x, (x + 1) / 2)  # parent basis at the children's support points
+    if ttype == CGP:  # the dof at the left end of a step belongs to the previous step
+        P = np.vstack([left[1:, 1:], right[1:, 1:]])
+    else:
+        P = np.vstack([left, right])
+    n = P.shape[1]
+    out = np.zeros((n * nsteps, n * nsteps // 2))
+    for it in range(nsteps // 2):
+        out[2 * n * it:2 * n * (it + 1), n * it:n * (it + 1)] = P
+    return out
+
+
+def time_restriction(ttype, r, nsteps=2):
+    """get_time_restriction_matrix (fe_time.h:851-898).  cG (FE_Q): the parent's value at its support point, read
+    from the child the point lies in; dG (FE_DGQArbitraryNodes): L2 projection of the two children."""
+    x = _time_nodes(ttype, r)
+    if ttype == CGP:
+        eps = 1e-12
+        left = np.where((x <= 0.5 + eps)[:, None], _lagrange(x, np.clip(2 * x, 0, 1)), 0.0)
+        right = np.where((x >= 0.5 - eps)[:, None], _lagrange(x, np.clip(2 * x - 1, 0, 1)), 0.0)
+        R = np.hstack([left[1:, 1:], right[1:, 1:]])
+    else:
+        xq, wq = gauss(r + 2)
+        V = _lagrange(x, xq)
+        M = (V.T * wq) @ V
+        Pl, Pr = _lagrange(x, x / 2), _lagrange(x, (x + 1) / 2)
+        Minv = np.linalg.inv(M)
+        R = np.hstack([Minv @ Pl.T @ M / 2, Minv @ Pr.T @ M / 2])
+    n = R.shape[0]
+    out = np.zeros((n * nsteps // 2, n * nsteps))
+    for it in range(nsteps // 2):
+        out[n * it:n * (it + 1), 2 * n * it:2 * n * (it + 1)] = R
+    return out
+
+
+def time_projection(ttype, r_src, r_dst, nsteps=1):
+    """get_time_projection_matrix (fe_time.h:749-803): L2 projection between the temporal spaces of one step"""
+    xs, xd = _time_nodes(ttype, r_src), _time_nodes(ttype, r_dst)
+    xq, wq = gauss(max(r_src, r_dst) + 2)
+    Vs, Vd = _lagrange(xs, xq), _lagrange(xd, xq)
+    proj = np.linalg.inv((Vd.T * wq) @ Vd) @ ((Vd.T * wq) @ Vs)
+    nd, ns = (r_dst + 1, r_src + 1) if ttype == DG else (r_dst, r_src)
+    if ttype == DG:
+        out = np.zeros((nsteps * nd, nsteps * ns))
+        for it in range(nsteps):
+            out[it * nd:(it + 1) * nd, it * ns:(it + 1) * ns] = proj
+        return out
+    full = np.zeros((nsteps * nd + 1, nsteps * ns + 1))  # consecutive steps share their end point (later fills overwrite)
+    for it in range(nsteps):
+        full[it * nd:it * nd + nd + 1, it * ns:it * ns + ns + 1] = proj
+    return full[1:, 1:]
