@@ -102,6 +102,17 @@ SIGNATURES = {
     "stfem_time_prolongation_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
     "stfem_time_restriction_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
     "stfem_time_projection_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int32)]),
+    "stfem_poly_mg_sequence": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "stfem_mg_sequence": (C.c_int, [C.c_int] * 5 + [C.c_char] + [C.c_int] * 4 + [C.c_char_p, C.POINTER(C.c_int32)]),
+    "stfem_precondition_stmg_types": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "stfem_transfer_create": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    "stfem_transfer_destroy": (None, [_vp]),
+    "stfem_transfer_prolongate": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "stfem_transfer_restrict": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "stfem_transfer_interpolate": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "stfem_transfer_last_error": (C.c_char_p, []),
+    "stfem_transfer_line_matrices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
+    "stfem_vector_convert": (C.c_int, [_vp, _vp, _vp]),
     "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
     "stfem_vanka_destroy": (None, [_vp]),
     "stfem_vanka_n_classes": (C.c_int, [_vp]),
@@ -463,6 +474,82 @@ def dot(ctx, a, b, n_own=0, stream=None):
     out = C.c_double(0.0)
     _check(lib().stfem_dot(ctx._h, a._h, b._h, n_own, C.byref(out), stream), "stfem_dot")
     return out.value
+
+
+# ------------------------------------------------------------------ space-time multigrid (8 f-2)
+
+def get_poly_mg_sequence(k_max, k_min, sequence_type="decrease_by_one"):
+    """fe_time.cc:40-56; coarsest degree first"""
+    kind = {"bisect": 0, "decrease_by_one": 1, "go_to_one": 2}[sequence_type]
+    n = C.c_int32(0)
+    _check(lib().stfem_poly_mg_sequence(k_max, k_min, kind, None, C.byref(n)), "stfem_poly_mg_sequence")
+    out = (C.c_int32 * n.value)()
+    _check(lib().stfem_poly_mg_sequence(k_max, k_min, kind, out, C.byref(n)), "stfem_poly_mg_sequence")
+    return list(out)
+
+
+def get_mg_sequence(n_sp_lvl, k_seq, p_seq=(), n_timesteps_at_once=1, n_timesteps_at_once_min=1, lower_lvl="k",
+                    coarsening_type="space_and_time", time_before_space=False, use_p_multigrid_space=False,
+                    zip_from_back=True):
+    """fe_time.cc:58-124 -> string over 't' (tau), 'k', 'h', 'p' (MGType), coarsest transfer first"""
+    ct = {"space_or_time": 0, "space_and_time": 1}[coarsening_type]
+    args = (n_sp_lvl, len(k_seq), len(p_seq), n_timesteps_at_once, n_timesteps_at_once_min, lower_lvl.encode(), ct,
+            int(time_before_space), int(use_p_multigrid_space), int(zip_from_back))
+    n = C.c_int32(0)
+    _check(lib().stfem_mg_sequence(*args, None, C.byref(n)), "stfem_mg_sequence")
+    buf = C.create_string_buffer(n.value + 1)
+    _check(lib().stfem_mg_sequence(*args, buf, C.byref(n)), "stfem_mg_sequence")
+    return buf.raw[:n.value].decode()
+
+
+def get_precondition_stmg_types(mg_type_level, coarsening_type="space_and_time", time_before_space=False, smoother=1):
+    """fe_time.cc:126-150: smoother id per level (0 = identity, 1 = relaxation, 2 = Chebyshev)"""
+    ct = {"space_or_time": 0, "space_and_time": 1}[coarsening_type]
+    out = (C.c_int32 * (len(mg_type_level) + 1))()
+    _check(lib().stfem_precondition_stmg_types(mg_type_level.encode(), len(mg_type_level), ct, int(time_before_space),
+                                               smoother, out), "stfem_precondition_stmg_types")
+    return list(out)
+
+
+class MGTwoLevelTransfer:
+    """deal.II MGTwoLevelTransfer between two contexts as MGTwoLevelBlockTransfer uses it (stmg.h:38-110)."""
+
+    def __init__(self, fine, coarse):
+        self.fine, self.coarse = fine, coarse
+        h = _vp()
+        _check(lib().stfem_transfer_create(fine._h, coarse._h, C.byref(h)), "stfem_transfer_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.stfem_transfer_destroy(self._h)
+            self._h = None
+
+    def prolongate_and_add(self, dst, src, stream=None):
+        _check(lib().stfem_transfer_prolongate(self._h, dst._h, src._h, 1, stream), "stfem_transfer_prolongate")
+
+    def prolongate(self, dst, src, stream=None):
+        _check(lib().stfem_transfer_prolongate(self._h, dst._h, src._h, 0, stream), "stfem_transfer_prolongate")
+
+    def restrict_and_add(self, dst, src, stream=None):
+        _check(lib().stfem_transfer_restrict(self._h, dst._h, src._h, 1, stream), "stfem_transfer_restrict")
+
+    def interpolate(self, dst, src, stream=None):
+        _check(lib().stfem_transfer_interpolate(self._h, dst._h, src._h, stream), "stfem_transfer_interpolate")
+
+
+def transfer_line_matrices(ncell_fine, degree_fine, ncell_coarse, degree_coarse):
+    """(P [n_f x n_c], I [n_c x n_f]): the 1D factors of a space transfer, without constraints"""
+    n_f, n_c = degree_fine * ncell_fine + 1, degree_coarse * ncell_coarse + 1
+    P, I = np.zeros((n_f, n_c)), np.zeros((n_c, n_f))
+    _check(lib().stfem_transfer_line_matrices(ncell_fine, degree_fine, ncell_coarse, degree_coarse, _p(P), _p(I)),
+           "stfem_transfer_line_matrices")
+    return P, I
+
+
+def vector_convert(dst, src, stream=None):
+    """dst = src across contexts of different precision (stmg.h:1330-1343)"""
+    _check(lib().stfem_vector_convert(dst._h, src._h, stream), "stfem_vector_convert")
 
 
 # ------------------------------------------------------------------------------- Stokes (8a-14)

@@ -808,4 +808,62 @@ void coefficient_per_cell(const int32_t nc[3], const double *v, double c1, doubl
       }
 }
 
+// ---- level schedule of the space-time multigrid ----
+
+std::vector<int> poly_mg_sequence(int k_max, int k_min, int sequence_type)
+{
+  std::vector<int> degrees{k_max};
+  while (degrees.back() > k_min) {
+    const int prev = degrees.back();
+    if (sequence_type == 0) degrees.push_back(prev / 2);
+    else if (sequence_type == 1) degrees.push_back(prev - 1);
+    else if (sequence_type == 2) degrees.push_back(k_min);
+    else return {};
+  }
+  std::reverse(degrees.begin(), degrees.end());
+  return degrees;
+}
+
+std::string mg_sequence(int n_sp_lvl, int n_k, int n_p, int n_timesteps_at_once, int n_timesteps_at_once_min, char lower_lvl,
+                        int coarsening_type, bool time_before_space, bool use_p_multigrid_space, bool zip_from_back)
+{
+  int n_tau = 0;
+  for (int q = n_timesteps_at_once / n_timesteps_at_once_min; q > 1; q /= 2) ++n_tau;
+  const int n_kl = n_k - 1, n_pl = use_p_multigrid_space ? n_p - 1 : 0, n_hl = n_sp_lvl - 1;
+  const bool k_low = lower_lvl == 'k';
+  // the lower kind of each family comes first (= nearer the coarse end)
+  const std::string time_levels = k_low ? std::string(n_kl, 'k') + std::string(n_tau, 't') : std::string(n_tau, 't') + std::string(n_kl, 'k');
+  const std::string space_levels = k_low ? std::string(n_pl, 'p') + std::string(n_hl, 'h') : std::string(n_hl, 'h') + std::string(n_pl, 'p');
+  const std::string &a = time_before_space ? time_levels : space_levels, &b = time_before_space ? space_levels : time_levels;
+  std::string seq;
+  if (coarsening_type == 0) { // space_or_time: one family after the other
+    if (zip_from_back) seq = std::string(a.rbegin(), a.rend()) + std::string(b.rbegin(), b.rend());
+    else seq = a + b;
+    return seq;
+  }
+  // space_and_time: interleaved, zipped from the fine end if zip_from_back
+  const size_t n = std::max(a.size(), b.size());
+  for (size_t i = 0; i < n; ++i) {
+    if (i < a.size()) seq.push_back(zip_from_back ? a[a.size() - 1 - i] : a[i]);
+    if (i < b.size()) seq.push_back(zip_from_back ? b[b.size() - 1 - i] : b[i]);
+  }
+  if (zip_from_back) std::reverse(seq.begin(), seq.end());
+  return seq;
+}
+
+std::vector<int> precondition_stmg_types(const std::string &seq, int coarsening_type, bool time_before_space, int smoother)
+{
+  std::vector<int> ret(seq.size() + 1, smoother);
+  if (coarsening_type == 0 || seq.empty()) return ret;
+  auto space = [](char c) { return c == 'h' || c == 'p'; };
+  // of a (space, time) pair of transfers that together form one space-time coarsening only the first level smooths
+  for (size_t i = 0; i + 1 < seq.size(); ++i)
+    if (time_before_space ? (space(seq[i]) && !space(seq[i + 1])) : (!space(seq[i]) && space(seq[i + 1]))) {
+      ret[i] = smoother;
+      ret[i + 1] = 0;
+      ++i;
+    }
+  return ret;
+}
+
 } // namespace stfem

@@ -2,6 +2,7 @@
 // temporal matrices (fe_time.h of the reference), mesh and coefficient helpers.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace stfem {
@@ -56,6 +57,15 @@ int fe_time_weights_wave(int type, int r, double tau, int nsteps, Mat &A_lhs, Ma
 int time_prolongation(int type, int r, int nsteps, Mat &out, int &m, int &n);
 int time_restriction(int type, int r, int nsteps, Mat &out, int &m, int &n);
 int time_projection(int type, int r_src, int r_dst, int nsteps, Mat &out, int &m, int &n);
+
+// ---- level schedule of the space-time multigrid (fe_time.cc:17-150); levels are 't' (tau), 'k', 'h', 'p' like MGType ----
+// get_poly_mg_sequence: sequence_type 0 = bisect, 1 = decrease_by_one, 2 = go_to_one; coarsest first
+std::vector<int> poly_mg_sequence(int k_max, int k_min, int sequence_type);
+// get_mg_sequence: n_k / n_p = lengths of the temporal / spatial degree sequences; coarsest transfer first
+std::string mg_sequence(int n_sp_lvl, int n_k, int n_p, int n_timesteps_at_once, int n_timesteps_at_once_min, char lower_lvl,
+                        int coarsening_type, bool time_before_space, bool use_p_multigrid_space, bool zip_from_back);
+// get_precondition_stmg_types: one smoother id per level (0 = identity)
+std::vector<int> precondition_stmg_types(const std::string &mg_type_level, int coarsening_type, bool time_before_space, int smoother);
 
 // ---- mesh / coefficient ----
 void mesh_vertices(const int32_t gn[3], const double lo[3], const double up[3], double distort,

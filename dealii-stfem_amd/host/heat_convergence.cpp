@@ -4,10 +4,17 @@
 // (200 steps, restart 100, 1e-12) preconditioned by relaxation sweeps of the cell-patch Vanka smoother
 // (the reference preconditions with its space-time multigrid, SURVEY 8 f-2, not built: the errors do not depend
 // on the preconditioner, the iteration counts do).
+// With mg=1 the preconditioner is the reference's own: one V-cycle of the space-time multigrid (host/stfem/stmg.h), levels as
+// tests/tp_01.cc:170-200 derives them.  Options (key=value, anywhere): mg=0|1, mg_float=0|1 (multigrid in fp32, stmg.h:1330-1343),
+// coarsening=space_or_time|space_and_time, pmg=0|1, kmin=<lowest temporal degree>, relaxation=<omega, 0 = estimated>, variable=0|1, steps=<n>
 // Usage: heat_convergence <type 0 = cG | 1 = dG> <k> <refinement> <n_timesteps_at_once> [vanka sweeps = 2, 0 = none] [omega = 0.5]
 //                         [fe_degree = k + 1] [cells per direction = 2^refinement] [end_time = 1] [FGMRES steps = 200]
 // Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
+#include "stfem/stmg.h"
 #include "stfem/time_integrators.h"
+
+#include <cstring>
+#include <map>
 
 #include <cstdio>
 #include <cstdlib>
@@ -15,8 +22,18 @@
 using namespace stfem;
 using Number = double;
 
-int main(int argc, char **argv)
+int main(int argc_all, char **argv_all)
 {
+  std::map<std::string, std::string> opt;
+  std::vector<char *> pos;
+  for (int i = 0; i < argc_all; ++i) {
+    const char *eq = std::strchr(argv_all[i], '=');
+    if (i > 0 && eq) opt[std::string(argv_all[i], size_t(eq - argv_all[i]))] = eq + 1;
+    else pos.push_back(argv_all[i]);
+  }
+  const int argc = int(pos.size());
+  char **argv = pos.data();
+  auto option = [&](const char *key, const char *dflt) { return opt.count(key) ? opt[key] : std::string(dflt); };
   if (argc < 5) {
     std::fprintf(stderr, "usage: %s type k refinement n_timesteps_at_once [sweeps] [omega]\n", argv[0]);
     return 2;
@@ -92,7 +109,37 @@ int main(int argc, char **argv)
         time += nsteps * tau;
       }
     };
-    if (sweeps > 0) {
+    if (option("mg", "0") == "1") {
+      // tests/tp_01.cc:170-200: one mesh level per halving down to one cell, temporal degrees by bisection, tau levels down to one step
+      unsigned n_sp_lvl = 1;
+      for (int c = n; c % 2 == 0; c /= 2) ++n_sp_lvl;
+      const unsigned kmin = std::min<unsigned>(k, std::atoi(option("kmin", "1").c_str()));
+      const auto poly_time = get_poly_mg_sequence(k, kmin, PolynomialCoarseningSequenceType::bisect);
+      std::vector<unsigned> poly_space;
+      for (unsigned q : poly_time) poly_space.push_back(q + (fe_degree - k)); // get_fe_pmg_sequence: FE_Q(time degree + 1)
+      const bool use_pmg = option("pmg", "0") == "1";
+      const auto ctype = option("coarsening", "space_or_time") == "space_and_time" ? CoarseningType::space_and_time : CoarseningType::space_or_time;
+      const auto mg_type_level = get_mg_sequence(n_sp_lvl, poly_time, poly_space, nsteps, 1, MGType::tau, ctype, false, use_pmg, true);
+      PreconditionerGMGAdditionalData mg_data;
+      mg_data.relaxation = std::atof(option("relaxation", "0").c_str());
+      mg_data.variable = option("variable", "1") == "1";
+      mg_data.smoothing_steps = std::atoi(option("steps", "1").c_str());
+      std::fprintf(stderr, "levels:");
+      for (auto m : mg_type_level) std::fprintf(stderr, " %c", char(m));
+      std::fprintf(stderr, "\n");
+      auto with = [&](auto number_tag) {
+        using NP = decltype(number_tag);
+        STMGHierarchy<3, NP> mg(mesh, fe_degree, poly_space, type, tau, nsteps, mg_type_level, poly_time, mg_data, ctype, false, true);
+        for (unsigned l = 0; l < mg.operators.size(); ++l)
+          std::fprintf(stderr, "level %u: %llu x %u dofs, smoother %u, relaxation %.4f\n", l, (unsigned long long)mg.K[l]->m(), mg.fetw[l][0].m(),
+                       mg.gmg->smoother_types()[l], mg.gmg->relaxation(l));
+        using P = GMG<3, NP, typename STMGHierarchy<3, NP>::System>;
+        TimeIntegratorFO<Number, SystemN, SystemN, P> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, *mg.gmg, rhs_matrix, source, nsteps, true, 1e-12, max_steps);
+        run(step);
+      };
+      if (option("mg_float", "0") == "1") with(float());
+      else with(double());
+    } else if (sweeps > 0) {
       PreconditionVanka<Number> vanka(K_mf, Alpha, Beta);
       PreconditionRelaxation<Number, SystemN> precond(matrix, vanka, omega, sweeps);
       TimeIntegratorFO<Number, SystemN, SystemN, decltype(precond)> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps, true, 1e-12, max_steps);

@@ -1,0 +1,545 @@
+// Host-side mirror of the reference's space-time multigrid (include/stmg.h:38-617 transfers,
+// 968-1419 PreconditionSTMG / GMG; include/fe_time.cc:17-150 and fe_time.h:412-443 level schedule) on the C-ABI.
+// The reference assembles it from deal.II parts (MGTwoLevelTransfer, Multigrid, MGSmootherPrecondition,
+// PreconditionRelaxation, MGCoarseGridApplySmoother, PreconditionMG); their control flow is restated here, every
+// vector operation runs on the device: level operators = the fused space-time sweep, smoother = the Vanka apply,
+// space transfers = stfem_transfer_* (three banded 1D passes), time transfers = stfem_tensorproduct_add.
+#pragma once
+#include "stokes.h"
+#include "time_integrators.h"
+
+#include <algorithm>
+#include <memory>
+#include <variant>
+
+namespace stfem {
+
+enum class MGType : char { tau = 't', k = 'k', h = 'h', p = 'p' };                      // fe_time.h:29-35
+enum class CoarseningType : int { space_or_time = 0, space_and_time = 1 };              // types.h:102-106
+enum class SupportedSmoothers : unsigned { Identity = 0, Relaxation = 1, Chebyshev = 2 }; // types.h:108-113
+enum class PolynomialCoarseningSequenceType { bisect = 0, decrease_by_one = 1, go_to_one = 2 };
+inline bool is_space_lvl(MGType mg) { return mg == MGType::h || mg == MGType::p; }
+inline bool is_time_lvl(MGType mg) { return mg == MGType::tau || mg == MGType::k; }
+
+// fe_time.cc:40-56
+inline std::vector<unsigned> get_poly_mg_sequence(unsigned k_max, unsigned k_min, PolynomialCoarseningSequenceType p_seq)
+{
+  int32_t n = 0;
+  check(stfem_poly_mg_sequence(int(k_max), int(k_min), int(p_seq), nullptr, &n), "get_poly_mg_sequence");
+  std::vector<int32_t> s(n);
+  check(stfem_poly_mg_sequence(int(k_max), int(k_min), int(p_seq), s.data(), &n), "get_poly_mg_sequence");
+  return std::vector<unsigned>(s.begin(), s.end());
+}
+
+// fe_time.cc:58-124
+inline std::vector<MGType> get_mg_sequence(unsigned n_sp_lvl, const std::vector<unsigned> &k_seq, const std::vector<unsigned> &p_seq,
+                                           unsigned n_timesteps_at_once, unsigned n_timesteps_at_once_min = 1, MGType lower_lvl = MGType::k,
+                                           CoarseningType coarsening_type = CoarseningType::space_and_time, bool time_before_space = false,
+                                           bool use_p_multigrid_space = false, bool zip_from_back = true)
+{
+  auto call = [&](char *out, int32_t *n) {
+    return stfem_mg_sequence(int(n_sp_lvl), int(k_seq.size()), int(p_seq.size()), int(n_timesteps_at_once), int(n_timesteps_at_once_min),
+                             char(lower_lvl), int(coarsening_type), time_before_space, use_p_multigrid_space, zip_from_back, out, n);
+  };
+  int32_t n = 0;
+  check(call(nullptr, &n), "get_mg_sequence");
+  std::string s(size_t(n), ' ');
+  check(call(s.data(), &n), "get_mg_sequence");
+  std::vector<MGType> r;
+  for (char c : s) r.push_back(MGType(c));
+  return r;
+}
+
+// fe_time.cc:126-150
+inline std::vector<unsigned> get_precondition_stmg_types(const std::vector<MGType> &mg_type_level, CoarseningType coarsening_type,
+                                                         bool time_before_space, bool /*zip_from_back*/,
+                                                         SupportedSmoothers smoother = SupportedSmoothers::Relaxation)
+{
+  std::string s;
+  for (MGType m : mg_type_level) s.push_back(char(m));
+  std::vector<int32_t> out(s.size() + 1);
+  check(stfem_precondition_stmg_types(s.data(), int(s.size()), int(coarsening_type), time_before_space, int(smoother), out.data()),
+        "get_precondition_stmg_types");
+  return std::vector<unsigned>(out.begin(), out.end());
+}
+
+// stmg.h:460-501: block structure of every level, finest last
+inline std::vector<BlockSlice> get_blk_indices(TimeStepType type, unsigned n_timesteps_at_once, unsigned n_variables, unsigned n_levels,
+                                               const std::vector<MGType> &mg_type_level, const std::vector<unsigned> &poly_time_sequence)
+{
+  if (mg_type_level.size() + 1 != n_levels) throw std::invalid_argument("get_blk_indices: n_levels - 1 transfers expected");
+  std::vector<BlockSlice> blk(n_levels);
+  auto p_mg = poly_time_sequence.rbegin();
+  auto dofs = [&](unsigned r) { return type == TimeStepType::DG ? r + 1 : r; };
+  unsigned i = n_levels - 1;
+  for (auto mgt = mg_type_level.rbegin(); mgt != mg_type_level.rend(); ++mgt, --i) {
+    blk[i] = BlockSlice(n_timesteps_at_once, n_variables, dofs(*p_mg));
+    if (*mgt == MGType::k) ++p_mg;
+    else if (*mgt == MGType::tau) n_timesteps_at_once /= 2;
+  }
+  if (p_mg != poly_time_sequence.rend() - 1) throw std::logic_error("get_blk_indices: degree sequence and k levels disagree");
+  blk[0] = BlockSlice(n_timesteps_at_once, n_variables, dofs(*p_mg));
+  return blk;
+}
+
+// fe_time.h:412-443: temporal matrices of every level, finest last
+template <typename Number>
+std::vector<std::array<FullMatrix<Number>, 4>> get_fe_time_weights(TimeStepType type, double time_step_size, unsigned n_timesteps_at_once,
+                                                                   const std::vector<MGType> &mg_type_level,
+                                                                   const std::vector<unsigned> &poly_time_sequence)
+{
+  std::vector<std::array<FullMatrix<Number>, 4>> tw(mg_type_level.size() + 1);
+  auto t = tw.rbegin();
+  auto p_mg = poly_time_sequence.rbegin();
+  *t++ = get_fe_time_weights<Number>(type, *p_mg, time_step_size, n_timesteps_at_once);
+  for (auto mgt = mg_type_level.rbegin(); mgt != mg_type_level.rend(); ++mgt, ++t) {
+    if (*mgt == MGType::k) ++p_mg;
+    else if (*mgt == MGType::tau) n_timesteps_at_once /= 2, time_step_size *= 2;
+    *t = get_fe_time_weights<Number>(type, *p_mg, time_step_size, n_timesteps_at_once);
+  }
+  return tw;
+}
+
+// parameters.h:11-31
+struct PreconditionerGMGAdditionalData {
+  double smoothing_range = 1;
+  unsigned smoothing_degree = 5, smoothing_eig_cg_n_iterations = 20, smoothing_steps = 1;
+  double relaxation = 0.0; // 0: estimated from the largest eigenvalue of P^-1 A (deal.II PreconditionRelaxation)
+  std::string coarse_grid_smoother_type = "Smoother";
+  SupportedSmoothers smoother = SupportedSmoothers::Relaxation;
+  bool restrict_is_transpose_prolongate = true;
+  bool variable = true;
+};
+
+// deal.II MGTwoLevelTransfer between the spaces of two contexts (h, p or both)
+template <typename Number> class MGTwoLevelTransfer {
+public:
+  MGTwoLevelTransfer(const std::shared_ptr<Context> &fine, const std::shared_ptr<Context> &coarse) : fine_(fine), coarse_(coarse)
+  {
+    stfem_transfer *t = nullptr;
+    const int rc = stfem_transfer_create(fine->h, coarse->h, &t);
+    if (rc != STFEM_OK) throw Error(rc, std::string("stfem_transfer_create: ") + stfem_transfer_last_error());
+    t_.reset(t, stfem_transfer_destroy);
+  }
+  stfem_transfer *handle() const { return t_.get(); }
+
+private:
+  std::shared_ptr<Context> fine_, coarse_;
+  std::shared_ptr<stfem_transfer> t_;
+};
+
+// stmg.h:38-110 (one variable: every block is transferred alike, all blocks in one call)
+template <typename Number> class MGTwoLevelTransferSpace {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  MGTwoLevelTransferSpace() = default;
+  MGTwoLevelTransferSpace(const BlockSlice &blk_index, const std::shared_ptr<MGTwoLevelTransfer<Number>> &transfer)
+    : blk_index(blk_index), transfer(transfer)
+  {}
+  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    check(stfem_transfer_prolongate(transfer->handle(), dst.handle(), src.handle(), 1, nullptr), "MGTwoLevelTransferSpace::prolongate_and_add");
+  }
+  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    check(stfem_transfer_restrict(transfer->handle(), dst.handle(), src.handle(), 1, nullptr), "MGTwoLevelTransferSpace::restrict_and_add");
+  }
+  void interpolate(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    check(stfem_transfer_interpolate(transfer->handle(), dst.handle(), src.handle(), nullptr), "MGTwoLevelTransferSpace::interpolate");
+  }
+
+private:
+  BlockSlice blk_index;
+  std::shared_ptr<MGTwoLevelTransfer<Number>> transfer;
+};
+
+// stmg.h:113-247
+template <typename Number> class MGTwoLevelTransferTime {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  MGTwoLevelTransferTime() = default;
+  MGTwoLevelTransferTime(const BlockSlice &blk_index_hi_, const BlockSlice &blk_index_lo_, TimeStepType type,
+                         bool restrict_is_transpose_prolongate, MGType mg_type)
+    : blk_index_hi(blk_index_hi_), blk_index_lo(blk_index_lo_)
+  {
+    if ((blk_index_hi.n_timedofs() == blk_index_lo.n_timedofs()) == (blk_index_hi.n_timesteps_at_once() == blk_index_lo.n_timesteps_at_once()))
+      throw std::logic_error("MGTwoLevelTransferTime: exactly one of degree and step count changes");
+    if (mg_type != MGType::k && mg_type != MGType::tau) throw std::invalid_argument("MGTwoLevelTransferTime: k or tau");
+    const bool k_mg = mg_type == MGType::k, dg = type == TimeStepType::DG;
+    const unsigned r = dg ? blk_index_hi.n_timedofs() - 1 : blk_index_hi.n_timedofs();
+    const unsigned r_lo = dg ? blk_index_lo.n_timedofs() - 1 : blk_index_lo.n_timedofs();
+    const unsigned n = blk_index_hi.n_timesteps_at_once();
+    prolongation_matrix = k_mg ? get_time_projection_matrix<Number>(type, r_lo, r, n) : get_time_prolongation_matrix<Number>(type, r, n);
+    interpolate_down_matrix = k_mg ? get_time_projection_matrix<Number>(type, r, r_lo, n) : get_time_restriction_matrix<Number>(type, r, n);
+    const FullMatrix<Number> &source = restrict_is_transpose_prolongate ? prolongation_matrix : interpolate_down_matrix;
+    if (restrict_is_transpose_prolongate) {
+      restriction_matrix = FullMatrix<Number>(source.n(), source.m());
+      for (unsigned i = 0; i < source.m(); ++i)
+        for (unsigned j = 0; j < source.n(); ++j) restriction_matrix(j, i) = source(i, j);
+    } else restriction_matrix = source;
+  }
+  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src) const { transfer_and_add(dst, blk_index_hi, prolongation_matrix, src, blk_index_lo); }
+  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src) const { transfer_and_add(dst, blk_index_lo, restriction_matrix, src, blk_index_hi); }
+  void interpolate(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    if (dst.n_blocks() > src.n_blocks()) throw std::invalid_argument("Interpolation only from fine to coarse");
+    axpby(0.0, dst, 0.0, dst);
+    transfer_and_add(dst, blk_index_lo, interpolate_down_matrix, src, blk_index_hi);
+  }
+  const FullMatrix<Number> &prolongation() const { return prolongation_matrix; }
+  const FullMatrix<Number> &restriction() const { return restriction_matrix; }
+
+private:
+  void transfer_and_add(BlockVectorType &dst, const BlockSlice &blk_dst, const FullMatrix<Number> &matrix, const BlockVectorType &src,
+                        const BlockSlice &blk_src) const
+  {
+    if (blk_src.n_variables() != 1) throw std::invalid_argument("MGTwoLevelTransferTime: one variable");
+    if (matrix.n() != src.n_blocks() || matrix.m() != dst.n_blocks() || blk_src.n_blocks() != src.n_blocks() || blk_dst.n_blocks() != dst.n_blocks())
+      throw std::invalid_argument("MGTwoLevelTransferTime: block counts");
+    std::vector<double> a(size_t(matrix.m()) * matrix.n());
+    for (size_t i = 0; i < a.size(); ++i) a[i] = double(matrix.data()[i]);
+    check(stfem_tensorproduct_add(dst.context()->h, int(matrix.m()), int(matrix.n()), a.data(), dst.handle(), src.handle(), nullptr),
+          "MGTwoLevelTransferTime: tensorproduct_add");
+  }
+  BlockSlice blk_index_hi, blk_index_lo;
+  FullMatrix<Number> prolongation_matrix, restriction_matrix, interpolate_down_matrix;
+};
+
+// stmg.h:249-302
+template <typename Number> class TwoLevelTransferOperator {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  TwoLevelTransferOperator() = default;
+  TwoLevelTransferOperator(const MGTwoLevelTransferSpace<Number> &t) : transfer_variant(t) {}
+  TwoLevelTransferOperator(const MGTwoLevelTransferTime<Number> &t) : transfer_variant(t) {}
+  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    std::visit([&](auto &t) { t.prolongate_and_add(dst, src); }, transfer_variant);
+  }
+  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    std::visit([&](auto &t) { t.restrict_and_add(dst, src); }, transfer_variant);
+  }
+  void interpolate(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    std::visit([&](auto &t) { t.interpolate(dst, src); }, transfer_variant);
+  }
+
+private:
+  std::variant<MGTwoLevelTransferSpace<Number>, MGTwoLevelTransferTime<Number>> transfer_variant;
+};
+
+// stmg.h:304-458: transfer[l] connects level l - 1 and level l
+template <typename Number> class STMGTransferBlockMatrixFree {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  STMGTransferBlockMatrixFree(std::vector<TwoLevelTransferOperator<Number>> transfers, std::vector<BlockSlice> blk_indices,
+                              std::vector<std::shared_ptr<Context>> level_contexts)
+    : transfer(std::move(transfers)), blk_indices(std::move(blk_indices)), contexts(std::move(level_contexts))
+  {}
+  void prolongate(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    axpby(0.0, dst, 0.0, dst);
+    prolongate_and_add(to_level, dst, src);
+  }
+  void prolongate_and_add(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[to_level].prolongate_and_add(dst, src); }
+  void restrict_and_add(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[from_level].restrict_and_add(dst, src); }
+  void interpolate(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[from_level].interpolate(dst, src); }
+  // copy_to_mg (stmg.h:401-415): every level vector sized and zeroed, the finest takes src
+  void copy_to_mg(std::vector<BlockVectorType> &dst, const BlockVectorType &src) const
+  {
+    dst.resize(blk_indices.size());
+    for (size_t l = 0; l < dst.size(); ++l) {
+      if (!dst[l].handle() || dst[l].n_blocks() != blk_indices[l].n_blocks()) dst[l].reinit(contexts[l], blk_indices[l].n_blocks());
+      else if (l + 1 < dst.size()) axpby(0.0, dst[l], 0.0, dst[l]);
+    }
+    axpby(1.0, src, 0.0, dst.back());
+  }
+  unsigned n_levels() const { return unsigned(blk_indices.size()); }
+  const BlockSlice &blk(unsigned l) const { return blk_indices[l]; }
+  const std::shared_ptr<Context> &context(unsigned l) const { return contexts[l]; }
+
+private:
+  std::vector<TwoLevelTransferOperator<Number>> transfer; // [0] unused
+  std::vector<BlockSlice> blk_indices;
+  std::vector<std::shared_ptr<Context>> contexts;
+};
+
+// The largest eigenvalue of P^-1 A by deal.II's power iteration (what PreconditionRelaxation does when its
+// relaxation parameter is 0, as the reference leaves it: parameters.h:19, stmg.h:1207-1213): start vector
+// (i mod 11) - mean on every block, n_iterations steps; relaxation = 2 / (0.9 lambda + lambda) for smoothing_range <= 1
+template <typename Number, typename Operator, typename Precond>
+double estimate_relaxation(const Operator &A, const Precond &P, unsigned n_iterations, double smoothing_range)
+{
+  BlockVectorT<Number> v, w, z;
+  A.initialize_dof_vector(v);
+  A.initialize_dof_vector(w);
+  A.initialize_dof_vector(z);
+  const size_t n = v.block_size();
+  std::vector<double> guess(n);
+  double mean = 0.0;
+  for (size_t i = 0; i < n; ++i) mean += double(i % 11);
+  mean /= double(n);
+  for (size_t i = 0; i < n; ++i) guess[i] = double(i % 11) - mean;
+  v.copy_from_host(std::vector<std::vector<double>>(v.n_blocks(), guess));
+  axpby(0.0, v, 1.0 / norm(v), v);
+  double lambda = 0.0;
+  for (unsigned it = 0; it < n_iterations; ++it) {
+    A.vmult(z, v);
+    P.vmult(w, z);
+    lambda = dot(v, w);
+    const double nw = norm(w);
+    if (!(nw > 0)) break;
+    axpby(1.0 / nw, w, 0.0, v);
+  }
+  lambda = std::abs(lambda);
+  const double alpha = smoothing_range > 1.0 ? lambda / smoothing_range : 0.9 * lambda;
+  return 2.0 / (alpha + lambda);
+}
+
+// stmg.h:968-1045 PreconditionSTMG: the smoother of one level - identity, or relaxation sweeps of the Vanka smoother
+// (PreconditionChebyshev, the third alternative of the reference, is not built)
+template <typename Number, typename LevelMatrixType> class PreconditionSTMG {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  PreconditionSTMG() = default;
+  void initialize(const LevelMatrixType &matrix, const std::shared_ptr<PreconditionVanka<Number>> &vanka, double relaxation, unsigned n_iterations)
+  {
+    relax = std::make_unique<PreconditionRelaxation<Number, LevelMatrixType>>(matrix, *vanka, relaxation, n_iterations);
+    keep = vanka;
+    omega = relaxation;
+  }
+  void vmult(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    if (relax) relax->vmult(dst, src);
+    else axpby(1.0, src, 0.0, dst);
+  }
+  void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
+  bool is_identity() const { return !relax; }
+  double relaxation() const { return omega; }
+
+private:
+  std::unique_ptr<PreconditionRelaxation<Number, LevelMatrixType>> relax;
+  std::shared_ptr<PreconditionVanka<Number>> keep;
+  double omega = 1.0;
+};
+
+// stmg.h:1047-1419 GMG: the V-cycle as FGMRES preconditioner.  Restates what the reference assembles from deal.II:
+// PreconditionMG::vmult (copy_to_mg, cycle, copy_from_mg), Multigrid::level_v_step, MGSmootherPrecondition
+// (steps = 1, variable: 2^(max_level - level) steps on level `level`) and MGCoarseGridApplySmoother.
+template <int dim, typename Number, typename LevelMatrixType> class GMG {
+public:
+  using BlockVectorType = BlockVectorT<Number>;
+  GMG(const PreconditionerGMGAdditionalData &additional_data, TimeStepType type, unsigned n_timesteps_at_once,
+      const std::vector<MGType> &mg_type_level, const std::vector<unsigned> &poly_time_sequence, CoarseningType coarsening_type,
+      bool time_before_space, bool space_time_level_first, const std::vector<std::shared_ptr<const LevelMatrixType>> &mg_operators,
+      const std::vector<std::shared_ptr<PreconditionVanka<Number>>> &mg_smoother_)
+    : additional_data(additional_data), mg_sequence(mg_type_level),
+      precondition_sequence(get_precondition_stmg_types(mg_type_level, coarsening_type, time_before_space, space_time_level_first, additional_data.smoother)),
+      mg_operators(mg_operators), precondition_vanka(mg_smoother_)
+  {
+    const unsigned n_levels = unsigned(mg_operators.size());
+    if (additional_data.coarse_grid_smoother_type != "Smoother") throw std::invalid_argument("GMG: only the smoother as coarse solver is built");
+    if (additional_data.smoother == SupportedSmoothers::Chebyshev) throw std::invalid_argument("GMG: the Chebyshev smoother is not built");
+    std::vector<BlockSlice> blk_indices = get_blk_indices(type, n_timesteps_at_once, 1u, n_levels, mg_type_level, poly_time_sequence);
+    // build_stmg_transfers (stmg.h:503-617)
+    std::vector<std::shared_ptr<Context>> contexts(n_levels);
+    for (unsigned l = 0; l < n_levels; ++l) {
+      BlockVectorType probe;
+      mg_operators[l]->initialize_dof_vector(probe);
+      contexts[l] = probe.context();
+      if (probe.n_blocks() != blk_indices[l].n_blocks()) throw std::invalid_argument("GMG: level operator and block structure disagree");
+    }
+    std::vector<TwoLevelTransferOperator<Number>> transfers(n_levels);
+    for (unsigned l = n_levels - 1; l >= 1; --l) {
+      const MGType mgt = mg_type_level[l - 1];
+      if (is_space_lvl(mgt))
+        transfers[l] = MGTwoLevelTransferSpace<Number>(blk_indices[l], std::make_shared<MGTwoLevelTransfer<Number>>(contexts[l], contexts[l - 1]));
+      else
+        transfers[l] = MGTwoLevelTransferTime<Number>(blk_indices[l], blk_indices[l - 1], type, additional_data.restrict_is_transpose_prolongate, mgt);
+    }
+    transfer_block = std::make_unique<STMGTransferBlockMatrixFree<Number>>(std::move(transfers), std::move(blk_indices), std::move(contexts));
+  }
+
+  // stmg.h:1190-1327 (the Relaxation / "Smoother" branches)
+  void reinit()
+  {
+    const unsigned n_levels = unsigned(mg_operators.size());
+    mg_smoother.clear();
+    mg_smoother.resize(n_levels);
+    for (unsigned l = 0; l < n_levels; ++l) {
+      if (precondition_sequence[l] == unsigned(SupportedSmoothers::Identity)) continue;
+      double omega = additional_data.relaxation;
+      if (omega == 0.0)
+        omega = estimate_relaxation<Number>(*mg_operators[l], *precondition_vanka[l], additional_data.smoothing_eig_cg_n_iterations,
+                                            additional_data.smoothing_range);
+      mg_smoother[l].initialize(*mg_operators[l], precondition_vanka[l], omega, additional_data.smoothing_steps);
+    }
+    defect.clear();
+    solution.clear();
+    t.clear();
+  }
+
+  // PreconditionMG::vmult; other vector types (the solver's double against the multigrid's float) go through src_ / dst_
+  // (stmg.h:1330-1343)
+  template <typename Number2> void vmult(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const
+  {
+    if constexpr (std::is_same<Number2, Number>::value) {
+      cycle(dst, src);
+    } else {
+      const auto &fine = transfer_block->context(transfer_block->n_levels() - 1);
+      if (!src_.handle()) {
+        src_.reinit(fine, src.n_blocks());
+        dst_.reinit(fine, src.n_blocks());
+      }
+      check(stfem_vector_convert(src_.handle(), src.handle(), nullptr), "stfem_vector_convert");
+      cycle(dst_, src_);
+      check(stfem_vector_convert(dst.handle(), dst_.handle(), nullptr), "stfem_vector_convert");
+    }
+  }
+  void interpolate(unsigned level, BlockVectorType &dst, const BlockVectorType &src) const { transfer_block->interpolate(level, dst, src); }
+  const STMGTransferBlockMatrixFree<Number> &transfer() const { return *transfer_block; }
+  double relaxation(unsigned level) const { return mg_smoother[level].relaxation(); }
+  const std::vector<unsigned> &smoother_types() const { return precondition_sequence; }
+
+private:
+  unsigned steps_on(unsigned level) const
+  {
+    const unsigned max_level = unsigned(mg_operators.size()) - 1;
+    return additional_data.variable ? 1u << (max_level - level) : 1u;
+  }
+  // MGSmootherPrecondition::apply (u is overwritten) / ::smooth (u is improved)
+  void smooth(unsigned level, BlockVectorType &u, const BlockVectorType &rhs, bool from_zero) const
+  {
+    const unsigned steps = steps_on(level);
+    BlockVectorType &r = t[level], &d = d_[level];
+    unsigned i = 0;
+    if (from_zero) {
+      mg_smoother[level].vmult(u, rhs);
+      i = 1;
+    }
+    for (; i < steps; ++i) {
+      mg_operators[level]->vmult(r, u);
+      axpby(1.0, rhs, -1.0, r);
+      mg_smoother[level].vmult(d, r);
+      axpby(1.0, d, 1.0, u);
+    }
+  }
+  // Multigrid::level_v_step
+  void level_v_step(unsigned level) const
+  {
+    if (level == 0) { // MGCoarseGridApplySmoother
+      smooth(0, solution[0], defect[0], true);
+      return;
+    }
+    smooth(level, solution[level], defect[level], true);
+    mg_operators[level]->vmult(t[level], solution[level]);
+    axpby(1.0, defect[level], -1.0, t[level]);
+    transfer_block->restrict_and_add(level, defect[level - 1], t[level]);
+    level_v_step(level - 1);
+    transfer_block->prolongate(level, t[level], solution[level - 1]);
+    axpby(1.0, t[level], 1.0, solution[level]);
+    smooth(level, solution[level], defect[level], false);
+  }
+  void cycle(BlockVectorType &dst, const BlockVectorType &src) const
+  {
+    transfer_block->copy_to_mg(defect, src);
+    const unsigned n_levels = transfer_block->n_levels();
+    if (solution.size() != n_levels) {
+      solution.resize(n_levels);
+      t.resize(n_levels);
+      d_.resize(n_levels);
+      for (unsigned l = 0; l < n_levels; ++l) {
+        solution[l].reinit(transfer_block->context(l), transfer_block->blk(l).n_blocks());
+        t[l].reinit(transfer_block->context(l), transfer_block->blk(l).n_blocks());
+        d_[l].reinit(transfer_block->context(l), transfer_block->blk(l).n_blocks());
+      }
+    }
+    level_v_step(n_levels - 1);
+    axpby(1.0, solution.back(), 0.0, dst); // copy_from_mg
+  }
+
+  PreconditionerGMGAdditionalData additional_data;
+  std::vector<MGType> mg_sequence;
+  std::vector<unsigned> precondition_sequence;
+  std::vector<std::shared_ptr<const LevelMatrixType>> mg_operators;
+  std::vector<std::shared_ptr<PreconditionVanka<Number>>> precondition_vanka;
+  std::unique_ptr<STMGTransferBlockMatrixFree<Number>> transfer_block;
+  std::vector<PreconditionSTMG<Number, LevelMatrixType>> mg_smoother;
+  mutable std::vector<BlockVectorType> defect, solution, t, d_;
+  mutable BlockVectorType src_, dst_;
+};
+
+// The level hierarchy as tests/tp_01.cc:170-330 sets it up: one mesh per h level (every second vertex plane of the
+// finer one: global coarsening of a refined mesh), FE_Q(space degree of the level), K = (0, 1) and M = (1, 0) operators,
+// the level's temporal matrices, the space-time operator and its Vanka smoother
+template <int dim, typename Number> struct STMGHierarchy {
+  using Operator = MatrixFreeOperatorScalar<dim, Number>;
+  using System = SystemMatrix<dim, Number, Operator>;
+  std::vector<MGType> mg_type_level;
+  std::vector<unsigned> poly_time_sequence;
+  std::vector<std::array<FullMatrix<Number>, 4>> fetw;
+  std::vector<std::shared_ptr<Operator>> K, M;
+  std::vector<std::shared_ptr<const System>> operators;
+  std::vector<std::shared_ptr<PreconditionVanka<Number>>> vanka;
+  std::unique_ptr<GMG<dim, Number, System>> gmg;
+
+  // poly_space_sequence: spatial degree per p level, coarsest first (used if the schedule holds 'p' transfers)
+  STMGHierarchy(const Mesh &fine_mesh, unsigned fe_degree_space, const std::vector<unsigned> &poly_space_sequence, TimeStepType type, double time_step_size,
+                unsigned n_timesteps_at_once, const std::vector<MGType> &mg_type_level_, const std::vector<unsigned> &poly_time_sequence_,
+                const PreconditionerGMGAdditionalData &mg_data, CoarseningType coarsening_type, bool time_before_space, bool space_time_level_first)
+    : mg_type_level(mg_type_level_), poly_time_sequence(poly_time_sequence_)
+  {
+    const unsigned n_levels = unsigned(mg_type_level.size()) + 1;
+    fetw = get_fe_time_weights<Number>(type, time_step_size, n_timesteps_at_once, mg_type_level, poly_time_sequence);
+    K.resize(n_levels);
+    M.resize(n_levels);
+    operators.resize(n_levels);
+    vanka.resize(n_levels);
+    Mesh mesh = fine_mesh;
+    unsigned degree = fe_degree_space;
+    auto p_it = poly_space_sequence.rbegin();
+    for (unsigned l = n_levels; l-- > 0;) {
+      const bool new_space = l == n_levels - 1 || is_space_lvl(mg_type_level[l]);
+      if (l < n_levels - 1 && mg_type_level[l] == MGType::h) mesh = coarsen(mesh);
+      if (l < n_levels - 1 && mg_type_level[l] == MGType::p) {
+        if (p_it == poly_space_sequence.rend() || ++p_it == poly_space_sequence.rend()) throw std::invalid_argument("STMGHierarchy: spatial degree sequence too short");
+        degree = *p_it;
+      }
+      if (new_space) {
+        K[l] = std::make_shared<Operator>(mesh, degree, 0.0, 1.0);
+        M[l] = std::make_shared<Operator>(*K[l], 1.0, 0.0);
+      } else {
+        K[l] = K[l + 1];
+        M[l] = M[l + 1];
+      }
+      operators[l] = std::make_shared<const System>(*K[l], *M[l], fetw[l][0], fetw[l][1]);
+      vanka[l] = std::make_shared<PreconditionVanka<Number>>(*K[l], fetw[l][0], fetw[l][1]);
+    }
+    gmg = std::make_unique<GMG<dim, Number, System>>(mg_data, type, n_timesteps_at_once, mg_type_level, poly_time_sequence, coarsening_type, time_before_space,
+                                                     space_time_level_first, operators, vanka);
+    gmg->reinit();
+  }
+
+  // one global coarsening step of a structured block: every second vertex plane
+  static Mesh coarsen(const Mesh &fine)
+  {
+    Mesh c = fine;
+    for (int d = 0; d < 3; ++d) {
+      if (fine.ncell[d] % 2) throw std::invalid_argument("STMGHierarchy: odd cell count, no coarser mesh");
+      c.ncell[d] = fine.ncell[d] / 2;
+    }
+    if (!fine.vertices.empty()) {
+      c.vertices.clear();
+      const size_t nvx = fine.ncell[0] + 1, nvy = fine.ncell[1] + 1;
+      for (int k = 0; k <= fine.ncell[2]; k += 2)
+        for (int j = 0; j <= fine.ncell[1]; j += 2)
+          for (int i = 0; i <= fine.ncell[0]; i += 2)
+            for (int e = 0; e < 3; ++e) c.vertices.push_back(fine.vertices[3 * (i + nvx * (j + nvy * size_t(k))) + e]);
+    }
+    return c;
+  }
+};
+
+} // namespace stfem

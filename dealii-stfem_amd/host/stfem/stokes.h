@@ -12,7 +12,7 @@ namespace stfem {
 // fe_time.h:901-1010 block_indexing / BlockSlice: block <-> (timestep, variable, timedof)
 class BlockSlice {
 public:
-  BlockSlice(unsigned n_timesteps_at_once, unsigned n_variables, unsigned n_timedofs, bool variable_major = true)
+  BlockSlice(unsigned n_timesteps_at_once = 1, unsigned n_variables = 1, unsigned n_timedofs = 1, bool variable_major = true)
     : nts_(n_timesteps_at_once), nv_(n_variables), ntd_(n_timedofs), variable_major_(variable_major)
   {}
   unsigned index(unsigned timestep, unsigned variable, unsigned timedof) const

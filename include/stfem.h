@@ -198,6 +198,44 @@ int stfem_time_prolongation_matrix(int type, int r, int n_timesteps_at_once, dou
 int stfem_time_restriction_matrix(int type, int r, int n_timesteps_at_once, double *out, int32_t dims[2]);
 int stfem_time_projection_matrix(int type, int r_src, int r_dst, int n_timesteps_at_once, double *out, int32_t dims[2]);
 
+/* Level schedule of the space-time multigrid (include/fe_time.cc:17-150).  Transfer kinds are the characters of the
+ * reference's MGType: 't' (tau: half the time steps per slab), 'k' (temporal degree), 'h' (mesh), 'p' (spatial degree);
+ * sequences list the coarsest transfer first.
+ * poly_mg_sequence: get_poly_mg_sequence(k_max, k_min, type), type 0 = bisect, 1 = decrease_by_one, 2 = go_to_one.
+ * mg_sequence: get_mg_sequence(n_sp_lvl, k_seq, p_seq, ...) - only the lengths n_k, n_p of the degree sequences
+ *   enter; lower_lvl 'k' or 't'; coarsening_type 0 = space_or_time, 1 = space_and_time (CoarseningType, types.h:102).
+ * precondition_stmg_types: get_precondition_stmg_types - n + 1 smoother ids (0 = identity: the level does not smooth).
+ * `out` may be NULL to ask for the length only (first two). */
+int stfem_poly_mg_sequence(int k_max, int k_min, int sequence_type, int32_t *out, int32_t *n_out);
+int stfem_mg_sequence(int n_sp_lvl, int n_k, int n_p, int n_timesteps_at_once, int n_timesteps_at_once_min, char lower_lvl,
+                      int coarsening_type, int time_before_space, int use_p_multigrid_space, int zip_from_back, char *out,
+                      int32_t *n_out);
+int stfem_precondition_stmg_types(const char *mg_type_level, int n, int coarsening_type, int time_before_space, int smoother,
+                                  int32_t *out);
+
+/* Space transfer between two levels (deal.II MGTwoLevelTransfer as the reference uses it: include/stmg.h:38-110,
+ * built in build_stmg_transfers, stmg.h:580-600): `fine` has per direction the same or twice the cells of `coarse`
+ * and a degree >= the coarse one (h-, p- or hp-transfer); both contexts on one device, same precision, their
+ * dirichlet masks are the constraints of the two levels.  All blocks of a block vector are transferred alike
+ * (MGTwoLevelBlockTransfer).
+ *   prolongate:  dst_fine (+)= P src_coarse  (embedding of the coarse space; constrained fine rows stay 0 / untouched)
+ *   restrict:    dst_coarse (+)= P^T src_fine  (restrict_and_add is add = 1)
+ *   interpolate: dst_coarse = the fine function at the coarse nodes (MGTwoLevelTransfer::interpolate)
+ * Asynchronous on `stream`; one transfer object serves one stream at a time (it owns the intermediates). */
+typedef struct stfem_transfer stfem_transfer;
+int stfem_transfer_create(stfem_ctx *fine, stfem_ctx *coarse, stfem_transfer **out);
+void stfem_transfer_destroy(stfem_transfer *t);
+int stfem_transfer_prolongate(stfem_transfer *t, stfem_vec *dst_fine, const stfem_vec *src_coarse, int add, void *stream);
+int stfem_transfer_restrict(stfem_transfer *t, stfem_vec *dst_coarse, const stfem_vec *src_fine, int add, void *stream);
+int stfem_transfer_interpolate(stfem_transfer *t, stfem_vec *dst_coarse, const stfem_vec *src_fine, void *stream);
+const char *stfem_transfer_last_error(void);
+/* the 1D factors a transfer is the Kronecker product of, without constraints (host only, for checks):
+ * P [n_f x n_c] embedding, I [n_c x n_f] nodal interpolation, n = degree * ncell + 1; either may be NULL */
+int stfem_transfer_line_matrices(int ncell_fine, int degree_fine, int ncell_coarse, int degree_coarse, double *P, double *I);
+/* dst = src between vectors of two contexts with the same number of DoFs, converting between fp64 and fp32
+ * (GMG::vmult, stmg.h:1330-1343: the multigrid runs in NumberPreconditioner, the solver in Number) */
+int stfem_vector_convert(stfem_vec *dst, const stfem_vec *src, void *stream);
+
 /* Cell-patch Vanka / additive-Schwarz smoother of the space-time system A = Alpha (x) K + Beta (x) M:
  * PreconditionVanka (include/stmg.h:619-907; set-up 786-829 with compute_block_matrix.h:50-139, apply
  * 832-872).  create: builds and inverts the valence-weighted cell blocks of the ASSEMBLED matrices (zero
