@@ -247,14 +247,14 @@ public:
   void restrict_and_add(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[from_level].restrict_and_add(dst, src); }
   void interpolate(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[from_level].interpolate(dst, src); }
   // copy_to_mg (stmg.h:401-415): every level vector sized and zeroed, the finest takes src
-  void copy_to_mg(std::vector<BlockVectorType> &dst, const BlockVectorType &src) const
+  template <typename Number2> void copy_to_mg(std::vector<BlockVectorType> &dst, const BlockVectorT<Number2> &src) const
   {
     dst.resize(blk_indices.size());
     for (size_t l = 0; l < dst.size(); ++l) {
       if (!dst[l].handle() || dst[l].n_blocks() != blk_indices[l].n_blocks()) dst[l].reinit(contexts[l], blk_indices[l].n_blocks());
       else if (l + 1 < dst.size()) axpby(0.0, dst[l], 0.0, dst[l]);
     }
-    axpby(1.0, src, 0.0, dst.back());
+    check(stfem_vector_convert(dst.back().handle(), src.handle(), nullptr), "copy_to_mg"); // copy_locally_owned_data_from
   }
   unsigned n_levels() const { return unsigned(blk_indices.size()); }
   const BlockSlice &blk(unsigned l) const { return blk_indices[l]; }
@@ -294,6 +294,7 @@ double estimate_relaxation(const Operator &A, const Precond &P, unsigned n_itera
     axpby(1.0 / nw, w, 0.0, v);
   }
   lambda = std::abs(lambda);
+  if (!(lambda > 0) || !std::isfinite(lambda)) return 1.0; // a level without free DoFs (one Q1 cell, all nodes constrained): nothing to relax
   const double alpha = smoothing_range > 1.0 ? lambda / smoothing_range : 0.9 * lambda;
   return 2.0 / (alpha + lambda);
 }
@@ -381,23 +382,9 @@ public:
     t.clear();
   }
 
-  // PreconditionMG::vmult; other vector types (the solver's double against the multigrid's float) go through src_ / dst_
-  // (stmg.h:1330-1343)
-  template <typename Number2> void vmult(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const
-  {
-    if constexpr (std::is_same<Number2, Number>::value) {
-      cycle(dst, src);
-    } else {
-      const auto &fine = transfer_block->context(transfer_block->n_levels() - 1);
-      if (!src_.handle()) {
-        src_.reinit(fine, src.n_blocks());
-        dst_.reinit(fine, src.n_blocks());
-      }
-      check(stfem_vector_convert(src_.handle(), src.handle(), nullptr), "stfem_vector_convert");
-      cycle(dst_, src_);
-      check(stfem_vector_convert(dst.handle(), dst_.handle(), nullptr), "stfem_vector_convert");
-    }
-  }
+  // PreconditionMG::vmult.  Vectors of another Number (the solver's double against the multigrid's float, stmg.h:1330-1343)
+  // or of another context on the same mesh are converted on the way into and out of the level vectors.
+  template <typename Number2> void vmult(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const { cycle(dst, src); }
   void interpolate(unsigned level, BlockVectorType &dst, const BlockVectorType &src) const { transfer_block->interpolate(level, dst, src); }
   const STMGTransferBlockMatrixFree<Number> &transfer() const { return *transfer_block; }
   double relaxation(unsigned level) const { return mg_smoother[level].relaxation(); }
@@ -442,7 +429,7 @@ private:
     axpby(1.0, t[level], 1.0, solution[level]);
     smooth(level, solution[level], defect[level], false);
   }
-  void cycle(BlockVectorType &dst, const BlockVectorType &src) const
+  template <typename Number2> void cycle(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const
   {
     transfer_block->copy_to_mg(defect, src);
     const unsigned n_levels = transfer_block->n_levels();
@@ -457,7 +444,7 @@ private:
       }
     }
     level_v_step(n_levels - 1);
-    axpby(1.0, solution.back(), 0.0, dst); // copy_from_mg
+    check(stfem_vector_convert(dst.handle(), solution.back().handle(), nullptr), "copy_from_mg");
   }
 
   PreconditionerGMGAdditionalData additional_data;
@@ -468,7 +455,6 @@ private:
   std::unique_ptr<STMGTransferBlockMatrixFree<Number>> transfer_block;
   std::vector<PreconditionSTMG<Number, LevelMatrixType>> mg_smoother;
   mutable std::vector<BlockVectorType> defect, solution, t, d_;
-  mutable BlockVectorType src_, dst_;
 };
 
 // The level hierarchy as tests/tp_01.cc:170-330 sets it up: one mesh per h level (every second vertex plane of the

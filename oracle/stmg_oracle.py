@@ -150,8 +150,12 @@ def power_iteration_relaxation(A, Pinv, nb, n, n_iterations=20, smoothing_range=
     for _ in range(n_iterations):
         w = Pinv(A @ v)
         lam = v @ w
+        if not np.linalg.norm(w) > 0:
+            break
         v = w / np.linalg.norm(w)
     lam = abs(lam)
+    if not lam > 0:  # a level without free DoFs
+        return 1.0
     alpha = lam / smoothing_range if smoothing_range > 1 else 0.9 * lam
     return 2.0 / (alpha + lam)
 

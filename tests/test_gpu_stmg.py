@@ -26,7 +26,7 @@ def rel(a, b):
     (3, (3, 2, 2), 1, (3, 2, 2), 63, 0.0),      # p-transfer
     (4, (2, 3, 2), 2, (2, 3, 2), 63 & ~48, 0.1),  # p-transfer on a perturbed slab with open z faces
     (2, (4, 2, 2), 1, (2, 1, 1), 0, 0.0),       # hp at once, no constraints
-    (1, (6, 4, 2), 1, (3, 2, 1), 63 & ~3, 0.12),  # Q1, perturbed
+    (1, (6, 4, 4), 1, (3, 2, 2), 63 & ~3, 0.12),  # Q1, perturbed
 ])
 def test_space_transfer_vs_oracle(pf, ncf, pc, ncc, mask, distort, number):
     from oracle import stmg_oracle
