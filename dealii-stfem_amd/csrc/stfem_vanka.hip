@@ -33,7 +33,7 @@
 namespace {
 
 constexpr int VK_MAX_BLOCKS = 8;
-constexpr int VK_MAX_ROWS = 384; // rows of a cell block (16 x 24 tiles)
+constexpr int VK_MAX_ROWS = 512; // rows of a cell block (16 x 32 tiles: Q4 with four temporal blocks = cG(2), two time steps per slab)
 constexpr long long VK_NO_ROW = -0x7fffffffffffffffll - 1; // offset-table entry of a row beyond the block (pointer differences may be negative)
 constexpr int KS = 16; // k rows of the inverse staged in LDS per step (two buffers)
 
@@ -575,7 +575,7 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
   if (!c || !Alpha || !Beta || !out || nb < 1 || nb > VK_MAX_BLOCKS) return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
-  if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 3 temporal blocks
+  if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 4 temporal blocks
   VK_TRY(hipSetDevice(c->device));
   stfem_vanka *v = new (std::nothrow) stfem_vanka;
   if (!v) return STFEM_ERR_OUT_OF_MEMORY;

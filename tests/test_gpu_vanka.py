@@ -14,18 +14,19 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("number", ["double", "float"])
-@pytest.mark.parametrize("p,nc,ttype,r,mask,upper", [
-    (2, (3, 3, 3), 0, 2, 63, (1.0, 1.0, 1.0)),
-    (1, (5, 4, 3), 1, 0, 63, (1.0, 2.0, 0.5)),   # one temporal block, anisotropic cells
-    (3, (4, 2, 3), 1, 1, 63 & ~48, (1.0, 1.0, 1.0)),  # dG(1), open z faces
-    (4, (3, 2, 2), 0, 2, 63, (1.0, 1.0, 1.0)),   # cfg 1's element: 250 x 250 blocks
-    (2, (1, 1, 1), 0, 2, 63, (1.0, 1.0, 1.0)),   # a single cell: the exact inverse
-    (2, (2, 1, 4), 0, 3, 63 & ~3, (1.0, 1.0, 1.0)),  # three temporal blocks, 81 rows -> padded tiles
+@pytest.mark.parametrize("p,nc,ttype,r,mask,upper,nsteps", [
+    (2, (3, 3, 3), 0, 2, 63, (1.0, 1.0, 1.0), 1),
+    (1, (5, 4, 3), 1, 0, 63, (1.0, 2.0, 0.5), 1),   # one temporal block, anisotropic cells
+    (3, (4, 2, 3), 1, 1, 63 & ~48, (1.0, 1.0, 1.0), 1),  # dG(1), open z faces
+    (4, (3, 2, 2), 0, 2, 63, (1.0, 1.0, 1.0), 1),   # cfg 1's element: 250 x 250 blocks
+    (4, (2, 2, 2), 0, 2, 63, (1.0, 1.0, 1.0), 2),  # cG(2) with two time steps per slab on Q4: 500 x 500 blocks
+    (2, (1, 1, 1), 0, 2, 63, (1.0, 1.0, 1.0), 1),   # a single cell: the exact inverse
+    (2, (2, 1, 4), 0, 3, 63 & ~3, (1.0, 1.0, 1.0), 1),  # three temporal blocks, 81 rows -> padded tiles
 ])
-def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, number):
+def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, nsteps, number):
     from oracle import vanka_oracle
     stfem = importlib.import_module("dealii-stfem_amd")
-    Alpha, Beta, _, _ = stfem.get_fe_time_weights(ttype, r, 0.05, 1)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(ttype, r, 0.05, nsteps)
     nb = Alpha.shape[0]
     ctx = stfem.MatrixFreeOperator(p, nc, lower=(0, 0, 0), upper=upper, number=number, dirichlet_mask=mask)
     V = stfem.PreconditionVanka(ctx, Alpha, Beta)
