@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -132,6 +133,84 @@ axis_apply_kernel(T *__restrict__ out, const T *__restrict__ in, int d0, int d1,
   }
 }
 
+
+// Cell form of the 1D passes along y and z (the bulk of the traffic): a thread takes one COARSE cell of a line - the local
+// embedding matrix L [(R + 1) x (PC + 1)] is the same for every cell, so the weights are kernel arguments (scalar registers),
+// the PC + 1 coarse values are loaded once for the R (+ 1) fine values they produce, and no index table is read.
+// Addressing: element (inner, i, outer) of an array with n entries along the axis at inner + S (i + n outer), inner < S contiguous.
+template <typename T> struct CellMat {
+  T L[9 * 5]; // L[j * (PC + 1) + a]
+};
+constexpr int CF_LO_C = 1, CF_HI_C = 2, CF_LO_F = 4, CF_HI_F = 8; // constrained ends of the coarse / fine line
+
+template <typename T, int PC, int R>
+__global__ void __launch_bounds__(256)
+cell_prolongate_kernel(T *__restrict__ out, const T *__restrict__ in, long long S, int ncell, long long total, const CellMat<T> m, int flags, int add)
+{
+  const long long n_c = (long long)PC * ncell + 1, n_f = (long long)R * ncell + 1;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long inner = t % S, rest = t / S;
+    const int c = int(rest % ncell);
+    const long long outer = rest / ncell;
+    const bool first = c == 0, last = c == ncell - 1;
+    T u[PC + 1];
+#pragma unroll
+    for (int a = 0; a <= PC; ++a) u[a] = in[inner + S * (c * (long long)PC + a + n_c * outer)];
+    if (first && (flags & CF_LO_C)) u[0] = T(0);
+    if (last && (flags & CF_HI_C)) u[PC] = T(0);
+    T *o = out + inner + S * (c * (long long)R + n_f * outer);
+#pragma unroll
+    for (int j = 0; j <= R; ++j) {
+      if (j == R && !last) break; // the upper end belongs to the next cell
+      T v = T(0);
+#pragma unroll
+      for (int a = 0; a <= PC; ++a) v += m.L[j * (PC + 1) + a] * u[a];
+      const bool constrained = (first && j == 0 && (flags & CF_LO_F)) || (last && j == R && (flags & CF_HI_F));
+      if (add) {
+        if (!constrained) o[S * j] += v;
+      } else o[S * j] = constrained ? T(0) : v;
+    }
+  }
+}
+
+// the transpose: coarse node a of cell c collects the fine values of its own cell and, for a = 0, of the interior of the cell before
+template <typename T, int PC, int R>
+__global__ void __launch_bounds__(256)
+cell_restrict_kernel(T *__restrict__ out, const T *__restrict__ in, long long S, int ncell, long long total, const CellMat<T> m, int flags, int add)
+{
+  const long long n_c = (long long)PC * ncell + 1, n_f = (long long)R * ncell + 1;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long inner = t % S, rest = t / S;
+    const int c = int(rest % ncell);
+    const long long outer = rest / ncell;
+    const bool first = c == 0, last = c == ncell - 1;
+    const T *f = in + inner + S * (c * (long long)R + n_f * outer);
+    T u[R + 1], w[R > 1 ? R - 1 : 1];
+#pragma unroll
+    for (int j = 0; j <= R; ++j) u[j] = f[S * j];
+#pragma unroll
+    for (int j = 1; j < R; ++j) w[j - 1] = first ? T(0) : f[S * (j - R)];
+    if (first && (flags & CF_LO_F)) u[0] = T(0);
+    if (last && (flags & CF_HI_F)) u[R] = T(0);
+    T *o = out + inner + S * (c * (long long)PC + n_c * outer);
+#pragma unroll
+    for (int a = 0; a <= PC; ++a) {
+      if (a == PC && !last) break;
+      T v = T(0);
+#pragma unroll
+      for (int j = (a == PC ? 1 : 0); j <= (a == 0 ? R - 1 : R); ++j) v += m.L[j * (PC + 1) + a] * u[j];
+      if (a == 0) {
+#pragma unroll
+        for (int j = 1; j < R; ++j) v += m.L[j * (PC + 1) + PC] * w[j - 1];
+      }
+      const bool constrained = (first && a == 0 && (flags & CF_LO_C)) || (last && a == PC && (flags & CF_HI_C));
+      if (add) {
+        if (!constrained) o[S * a] += v;
+      } else o[S * a] = constrained ? T(0) : v;
+    }
+  }
+}
+
 template <typename TD, typename TS> __global__ void convert_kernel(TD *__restrict__ d, const TS *__restrict__ s, long long n)
 {
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) d[t] = TD(s[t]);
@@ -142,6 +221,10 @@ template <typename TD, typename TS> __global__ void convert_kernel(TD *__restric
 struct stfem_transfer {
   stfem_ctx *fine = nullptr, *coarse = nullptr;
   Band P[3], R[3], I[3]; // per direction: prolongation rows, its transpose, nodal interpolation (all with the constraints)
+  // cell form of P / R along y and z: local embedding matrix, coarse degree, fine nodes per coarse cell, coarse cells, constrained ends
+  double L[3][9 * 5];
+  bool cell_form = true; // STFEM_TRANSFER_TABLES=1: table-driven passes along every axis (for comparison)
+  int pc[3] = {0, 0, 0}, Rn[3] = {0, 0, 0}, ncc[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
   void *d_tmp[2] = {nullptr, nullptr};
   size_t tmp_elems = 0;
 };
@@ -175,9 +258,38 @@ int launch_axis(T *out, const T *in, const int dims[3], int axis, const Band &b,
   return STFEM_OK;
 }
 
-// out (dims of `to`) (+)= (B2 (x) B1 (x) B0) in; order: the axes in `order`, smallest intermediates first
+
+template <typename T, int PC, int R>
+int launch_cell_t(bool prolongate, T *out, const T *in, long long S, int ncell, long long total, const double *L, int flags, int add, hipStream_t s)
+{
+  CellMat<T> m;
+  for (int i = 0; i < 9 * 5; ++i) m.L[i] = T(L[i]);
+  const int blocks = int(std::min<long long>((total + 255) / 256, 1 << 20));
+  if (prolongate) cell_prolongate_kernel<T, PC, R><<<blocks, 256, 0, s>>>(out, in, S, ncell, total, m, flags, add);
+  else cell_restrict_kernel<T, PC, R><<<blocks, 256, 0, s>>>(out, in, S, ncell, total, m, flags, add);
+  TR_TRY(hipGetLastError());
+  return STFEM_OK;
+}
+
+// returns 1 if there is no instantiation for (pc, R): the caller falls back to the table-driven kernel
 template <typename T>
-int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const int order[3], int add, hipStream_t s)
+int launch_cell(bool prolongate, int pc, int R, T *out, const T *in, long long S, int ncell, long long total, const double *L, int flags, int add,
+                hipStream_t s)
+{
+#define STFEM_CELL_CASE(PC_, R_) \
+  if (pc == PC_ && R == R_) return launch_cell_t<T, PC_, R_>(prolongate, out, in, S, ncell, total, L, flags, add, s);
+  STFEM_CELL_CASE(1, 2) STFEM_CELL_CASE(1, 3) STFEM_CELL_CASE(1, 4) STFEM_CELL_CASE(1, 6) STFEM_CELL_CASE(1, 8)
+  STFEM_CELL_CASE(2, 3) STFEM_CELL_CASE(2, 4) STFEM_CELL_CASE(2, 6) STFEM_CELL_CASE(2, 8)
+  STFEM_CELL_CASE(3, 4) STFEM_CELL_CASE(3, 6) STFEM_CELL_CASE(3, 8)
+  STFEM_CELL_CASE(4, 8)
+#undef STFEM_CELL_CASE
+  return 1;
+}
+
+// out (dims of `to`) (+)= (B2 (x) B1 (x) B0) in; order: the axes in `order`, smallest intermediates first
+// cell: 0 = table-driven passes only (interpolation), 1 = prolongation, 2 = restriction in cell form along y and z
+template <typename T>
+int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const int order[3], int add, int cell, hipStream_t s)
 {
   int dims[3] = {B[0].n_in, B[1].n_in, B[2].n_in};
   const T *cur = static_cast<const T *>(in);
@@ -185,7 +297,14 @@ int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const 
     const int ax = order[step];
     dims[ax] = B[ax].n_out;
     T *dst = step == 2 ? static_cast<T *>(out) : static_cast<T *>(t->d_tmp[step]);
-    const int st = launch_axis<T>(dst, cur, dims, ax, B[ax], step == 2 ? add : 0, s);
+    int st = 1;
+    if (cell && ax > 0 && t->Rn[ax] > t->pc[ax]) { // (an axis with the same cells and degree on both levels is a copy: table-driven)
+      const long long S = ax == 1 ? dims[0] : (long long)dims[0] * dims[1];
+      const long long total = S * t->ncc[ax] * (ax == 1 ? dims[2] : 1);
+      st = launch_cell<T>(cell == 1, t->pc[ax], t->Rn[ax], dst, cur, S, t->ncc[ax], total, t->L[ax], t->flags[ax], step == 2 ? add : 0, s);
+      if (st < 0) return st;
+    }
+    if (st == 1) st = launch_axis<T>(dst, cur, dims, ax, B[ax], step == 2 ? add : 0, s);
     if (st != STFEM_OK) return st;
     cur = dst;
   }
@@ -193,7 +312,7 @@ int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const 
 }
 
 int run(stfem_transfer *t, const Band B[3], stfem_ctx *to, stfem_ctx *from, stfem_vec *dst, const stfem_vec *src, bool expanding, int add,
-        void *stream)
+        void *stream, int cell = 0)
 {
   if (!t || !dst || !src) return STFEM_ERR_INVALID_ARGUMENT;
   if (dst->ctx != to || src->ctx != from || dst->nb != src->nb) return STFEM_ERR_SHAPE_MISMATCH;
@@ -201,8 +320,8 @@ int run(stfem_transfer *t, const Band B[3], stfem_ctx *to, stfem_ctx *from, stfe
   const int up[3] = {0, 1, 2}, down[3] = {2, 1, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   for (int b = 0; b < dst->nb; ++b) {
-    const int st = to->prec == 0 ? apply3<double>(t, B, dst->blk[b], src->blk[b], expanding ? up : down, add, s)
-                                 : apply3<float>(t, B, dst->blk[b], src->blk[b], expanding ? up : down, add, s);
+    const int st = to->prec == 0 ? apply3<double>(t, B, dst->blk[b], src->blk[b], expanding ? up : down, add, cell, s)
+                                 : apply3<float>(t, B, dst->blk[b], src->blk[b], expanding ? up : down, add, cell, s);
     if (st != STFEM_OK) return st;
   }
   return STFEM_OK;
@@ -227,9 +346,11 @@ int stfem_transfer_create(stfem_ctx *fine, stfem_ctx *coarse, stfem_transfer **o
   stfem_transfer *t = new stfem_transfer;
   t->fine = fine;
   t->coarse = coarse;
+  if (const char *e = getenv("STFEM_TRANSFER_TABLES")) t->cell_form = atoi(e) == 0;
   for (int d = 0; d < 3; ++d) {
     std::vector<double> P, I;
     line_matrices(fine->nc[d], fine->p, coarse->nc[d], coarse->p, P, I);
+    const std::vector<double> P0 = P;
     const int n_f = fine->nd[d], n_c = coarse->nd[d];
     // zero-boundary constraints of both levels: constrained rows are not written, constrained columns read as 0
     auto constrained = [&](const stfem_ctx *c, int i, int n) { return (i == 0 && (c->dmask >> (2 * d) & 1)) || (i == n - 1 && (c->dmask >> (2 * d + 1) & 1)); };
@@ -239,6 +360,14 @@ int stfem_transfer_create(stfem_ctx *fine, stfem_ctx *coarse, stfem_transfer **o
         if (constrained(fine, f, n_f) || constrained(coarse, c, n_c)) P[size_t(f) * n_c + c] = 0.0, I[size_t(c) * n_f + f] = 0.0;
         R[size_t(c) * n_f + f] = P[size_t(f) * n_c + c];
       }
+    // cell form: the block of cell 0 of the unconstrained embedding (the same in every cell)
+    t->pc[d] = coarse->p;
+    t->Rn[d] = (fine->nc[d] / coarse->nc[d]) * fine->p;
+    t->ncc[d] = coarse->nc[d];
+    t->flags[d] = (constrained(coarse, 0, n_c) ? CF_LO_C : 0) | (constrained(coarse, n_c - 1, n_c) ? CF_HI_C : 0) |
+                  (constrained(fine, 0, n_f) ? CF_LO_F : 0) | (constrained(fine, n_f - 1, n_f) ? CF_HI_F : 0);
+    for (int j = 0; j <= t->Rn[d]; ++j)
+      for (int a = 0; a <= t->pc[d]; ++a) t->L[d][j * (t->pc[d] + 1) + a] = P0[size_t(j) * n_c + a];
     t->P[d] = make_band(n_f, n_c, P);
     t->R[d] = make_band(n_c, n_f, R);
     t->I[d] = make_band(n_c, n_f, I);
@@ -277,11 +406,11 @@ void stfem_transfer_destroy(stfem_transfer *t)
 
 int stfem_transfer_prolongate(stfem_transfer *t, stfem_vec *dst_fine, const stfem_vec *src_coarse, int add, void *stream)
 {
-  return t ? run(t, t->P, t->fine, t->coarse, dst_fine, src_coarse, true, add, stream) : STFEM_ERR_INVALID_ARGUMENT;
+  return t ? run(t, t->P, t->fine, t->coarse, dst_fine, src_coarse, true, add, stream, t->cell_form ? 1 : 0) : STFEM_ERR_INVALID_ARGUMENT;
 }
 int stfem_transfer_restrict(stfem_transfer *t, stfem_vec *dst_coarse, const stfem_vec *src_fine, int add, void *stream)
 {
-  return t ? run(t, t->R, t->coarse, t->fine, dst_coarse, src_fine, false, add, stream) : STFEM_ERR_INVALID_ARGUMENT;
+  return t ? run(t, t->R, t->coarse, t->fine, dst_coarse, src_fine, false, add, stream, t->cell_form ? 2 : 0) : STFEM_ERR_INVALID_ARGUMENT;
 }
 int stfem_transfer_interpolate(stfem_transfer *t, stfem_vec *dst_coarse, const stfem_vec *src_fine, void *stream)
 {
