@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="N > 1: compare every rank's slab of the sharded vmult with a single-domain vmult of the "
                          "whole mesh computed on the same GPU (small meshes only)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3],
+                    help="1: BASELINE configs[1] / [2] (heat, the contract line); 3: configs[3] = wave equation, Q3 x dG(2), "
+                         "80^3 cells on [-1,1]^3 per GPU, Coefficient(1,9,16) per cell (extra line, not the contract metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU baseline mesh (0: as the GPU run)")
     args = ap.parse_args()
@@ -136,6 +139,10 @@ def main():
 
     if args.distort is None:
         args.distort = 0.0 if world == 1 else 0.15
+    if args.config == 3:
+        if world != 1:
+            raise SystemExit("--config 3 is a one-GPU line")
+        args.degree, args.time_degree, args.cells, args.distort, args.no_cpu_baseline = 3, 2, 80, 0.0, True
     p, r, n = args.degree, args.time_degree, args.cells
     if args.scaling == "strong":
         n = args.strong_cells
@@ -157,6 +164,13 @@ def main():
         ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=(0, 0, float(slab.z0) / n),
                                        upper=(1, 1, float(slab.z1) / n), number=args.number,
                                        dirichlet_mask=slab.dirichlet_mask(63), device=local_rank)
+    if args.config == 3:  # tests/tp_01.cc:141-150 (coefficient on K), fe_time.h:157-305 (wave matrices), SURVEY 8d: tau = 1/64
+        lo, up = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=lo, upper=up, number=args.number, device=local_rank)
+        coef = stfem.coefficient_per_cell(slab.ncell, stfem.mesh_vertices(slab.ncell, lo, up), 1.0, 9.0, 16.0, 0.0, (5, 5, 5), lo, up)
+        ctx.evaluate_coefficient(coef, which=1)
+        Alpha, Beta, _, _, _ = stfem.get_fe_time_weights_wave(stfem.DG, r, 1.0 / 64, 1)
+        nb = Alpha.shape[0]
     A = stfem.SystemMatrix(ctx, Alpha, Beta)
     ndofs = ctx.n_dofs
     nx = p * n + 1
@@ -317,17 +331,20 @@ def main():
                                  if (world, n, p, r, args.number) == (1, 72, 4, 2, "double") and args.distort in (0.0, 0.15)
                                  else (None, None))
         out = {
-            "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s",
+            "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s" if args.config == 1 else
+                      "space-time DoF/s per vmult (3D wave, Q3 space x dG(2) time); achieved HBM GB/s",
             "value": total_dofs * args.steps / elapsed,
             "unit": "space-time DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64" if args.number == "double" else "f32", "data": "synthetic",
-            "config": {"workload": f"3D heat, Q{p} x cG({r}), {global_nc[0]}x{global_nc[1]}x{global_nc[2]} cells "
-                                   + (f"perturbed ({args.distort} h vertex jitter)" if args.distort else "Cartesian")
-                                   + f" slab mesh, {total_dofs} space-time DoFs"
-                                   + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else "")
-                                   + (" = the BASELINE configs[2] mesh" if (global_nc, p, r, args.distort) == ((144, 144, 144), 4, 2, 0.15) else ""),
+            "config": {"workload": (f"3D wave, Q{p} x dG({r}), 80x80x80 cells on [-1,1]^3, Coefficient(1,9,16) per cell, {total_dofs} space-time DoFs "
+                                    "= BASELINE configs[3] on one GPU") if args.config == 3 else
+                                   (f"3D heat, Q{p} x cG({r}), {global_nc[0]}x{global_nc[1]}x{global_nc[2]} cells "
+                                    + (f"perturbed ({args.distort} h vertex jitter)" if args.distort else "Cartesian")
+                                    + f" slab mesh, {total_dofs} space-time DoFs"
+                                    + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else "")
+                                    + (" = the BASELINE configs[2] mesh" if (global_nc, p, r, args.distort) == ((144, 144, 144), 4, 2, 0.15) else "")),
                        "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
                        "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name,
                        # rank 0, per step: the local cell sweep and the packed interface-plane exchange
