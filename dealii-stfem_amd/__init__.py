@@ -113,6 +113,13 @@ SIGNATURES = {
     "stfem_transfer_last_error": (C.c_char_p, []),
     "stfem_transfer_line_matrices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "stfem_vector_convert": (C.c_int, [_vp, _vp, _vp]),
+    "stfem_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "stfem_stream_destroy": (None, [_vp]),
+    "stfem_stream_synchronize": (C.c_int, [_vp]),
+    "stfem_graph_begin": (C.c_int, [_vp]),
+    "stfem_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "stfem_graph_launch": (C.c_int, [_vp, _vp]),
+    "stfem_graph_destroy": (None, [_vp]),
     "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
     "stfem_vanka_destroy": (None, [_vp]),
     "stfem_vanka_n_classes": (C.c_int, [_vp]),

@@ -445,6 +445,65 @@ int stfem_vector_convert(stfem_vec *dst, const stfem_vec *src, void *stream)
   return STFEM_OK;
 }
 
+// ---- stream capture: a fixed sequence of launches (one V-cycle: ~1300 kernels, most of them on coarse levels where the
+// launch costs more than the kernel) recorded once into a hipGraph and replayed
+struct stfem_graph {
+  hipGraphExec_t exec = nullptr;
+};
+
+int stfem_stream_create(void **stream_out)
+{
+  if (!stream_out) return STFEM_ERR_INVALID_ARGUMENT;
+  hipStream_t s = nullptr;
+  TR_TRY(hipStreamCreate(&s)); // a blocking stream: ordered against the legacy default stream the other calls use
+  *stream_out = s;
+  return STFEM_OK;
+}
+void stfem_stream_destroy(void *stream)
+{
+  if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
+int stfem_stream_synchronize(void *stream)
+{
+  TR_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return STFEM_OK;
+}
+int stfem_graph_begin(void *stream)
+{
+  if (!stream) return STFEM_ERR_INVALID_ARGUMENT; // the legacy default stream cannot be captured
+  TR_TRY(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+  return STFEM_OK;
+}
+int stfem_graph_end(void *stream, stfem_graph **out)
+{
+  if (!stream || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  TR_TRY(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
+  stfem_graph *r = new stfem_graph;
+  const hipError_t e = hipGraphInstantiate(&r->exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    snprintf(g_transfer_err, sizeof(g_transfer_err), "hipGraphInstantiate: %s", hipGetErrorString(e));
+    delete r;
+    return STFEM_ERR_HIP;
+  }
+  *out = r;
+  return STFEM_OK;
+}
+int stfem_graph_launch(stfem_graph *g, void *stream)
+{
+  if (!g || !g->exec) return STFEM_ERR_INVALID_ARGUMENT;
+  TR_TRY(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+  return STFEM_OK;
+}
+void stfem_graph_destroy(stfem_graph *g)
+{
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  delete g;
+}
+
 int stfem_poly_mg_sequence(int k_max, int k_min, int sequence_type, int32_t *out, int32_t *n_out)
 {
   if (!n_out || k_min < 0 || k_max < k_min) return STFEM_ERR_INVALID_ARGUMENT;

@@ -136,17 +136,17 @@ public:
   MGTwoLevelTransferSpace(const BlockSlice &blk_index, const std::shared_ptr<MGTwoLevelTransfer<Number>> &transfer)
     : blk_index(blk_index), transfer(transfer)
   {}
-  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    check(stfem_transfer_prolongate(transfer->handle(), dst.handle(), src.handle(), 1, nullptr), "MGTwoLevelTransferSpace::prolongate_and_add");
+    check(stfem_transfer_prolongate(transfer->handle(), dst.handle(), src.handle(), 1, stream), "MGTwoLevelTransferSpace::prolongate_and_add");
   }
-  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    check(stfem_transfer_restrict(transfer->handle(), dst.handle(), src.handle(), 1, nullptr), "MGTwoLevelTransferSpace::restrict_and_add");
+    check(stfem_transfer_restrict(transfer->handle(), dst.handle(), src.handle(), 1, stream), "MGTwoLevelTransferSpace::restrict_and_add");
   }
-  void interpolate(BlockVectorType &dst, const BlockVectorType &src) const
+  void interpolate(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    check(stfem_transfer_interpolate(transfer->handle(), dst.handle(), src.handle(), nullptr), "MGTwoLevelTransferSpace::interpolate");
+    check(stfem_transfer_interpolate(transfer->handle(), dst.handle(), src.handle(), stream), "MGTwoLevelTransferSpace::interpolate");
   }
 
 private:
@@ -179,27 +179,33 @@ public:
         for (unsigned j = 0; j < source.n(); ++j) restriction_matrix(j, i) = source(i, j);
     } else restriction_matrix = source;
   }
-  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src) const { transfer_and_add(dst, blk_index_hi, prolongation_matrix, src, blk_index_lo); }
-  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src) const { transfer_and_add(dst, blk_index_lo, restriction_matrix, src, blk_index_hi); }
-  void interpolate(BlockVectorType &dst, const BlockVectorType &src) const
+  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    transfer_and_add(dst, blk_index_hi, prolongation_matrix, src, blk_index_lo, stream);
+  }
+  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    transfer_and_add(dst, blk_index_lo, restriction_matrix, src, blk_index_hi, stream);
+  }
+  void interpolate(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
     if (dst.n_blocks() > src.n_blocks()) throw std::invalid_argument("Interpolation only from fine to coarse");
-    axpby(0.0, dst, 0.0, dst);
-    transfer_and_add(dst, blk_index_lo, interpolate_down_matrix, src, blk_index_hi);
+    axpby(0.0, dst, 0.0, dst, stream);
+    transfer_and_add(dst, blk_index_lo, interpolate_down_matrix, src, blk_index_hi, stream);
   }
   const FullMatrix<Number> &prolongation() const { return prolongation_matrix; }
   const FullMatrix<Number> &restriction() const { return restriction_matrix; }
 
 private:
   void transfer_and_add(BlockVectorType &dst, const BlockSlice &blk_dst, const FullMatrix<Number> &matrix, const BlockVectorType &src,
-                        const BlockSlice &blk_src) const
+                        const BlockSlice &blk_src, void *stream) const
   {
     if (blk_src.n_variables() != 1) throw std::invalid_argument("MGTwoLevelTransferTime: one variable");
     if (matrix.n() != src.n_blocks() || matrix.m() != dst.n_blocks() || blk_src.n_blocks() != src.n_blocks() || blk_dst.n_blocks() != dst.n_blocks())
       throw std::invalid_argument("MGTwoLevelTransferTime: block counts");
     std::vector<double> a(size_t(matrix.m()) * matrix.n());
     for (size_t i = 0; i < a.size(); ++i) a[i] = double(matrix.data()[i]);
-    check(stfem_tensorproduct_add(dst.context()->h, int(matrix.m()), int(matrix.n()), a.data(), dst.handle(), src.handle(), nullptr),
+    check(stfem_tensorproduct_add(dst.context()->h, int(matrix.m()), int(matrix.n()), a.data(), dst.handle(), src.handle(), stream),
           "MGTwoLevelTransferTime: tensorproduct_add");
   }
   BlockSlice blk_index_hi, blk_index_lo;
@@ -213,17 +219,17 @@ public:
   TwoLevelTransferOperator() = default;
   TwoLevelTransferOperator(const MGTwoLevelTransferSpace<Number> &t) : transfer_variant(t) {}
   TwoLevelTransferOperator(const MGTwoLevelTransferTime<Number> &t) : transfer_variant(t) {}
-  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  void prolongate_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    std::visit([&](auto &t) { t.prolongate_and_add(dst, src); }, transfer_variant);
+    std::visit([&](auto &t) { t.prolongate_and_add(dst, src, stream); }, transfer_variant);
   }
-  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src) const
+  void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    std::visit([&](auto &t) { t.restrict_and_add(dst, src); }, transfer_variant);
+    std::visit([&](auto &t) { t.restrict_and_add(dst, src, stream); }, transfer_variant);
   }
-  void interpolate(BlockVectorType &dst, const BlockVectorType &src) const
+  void interpolate(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    std::visit([&](auto &t) { t.interpolate(dst, src); }, transfer_variant);
+    std::visit([&](auto &t) { t.interpolate(dst, src, stream); }, transfer_variant);
   }
 
 private:
@@ -238,23 +244,35 @@ public:
                               std::vector<std::shared_ptr<Context>> level_contexts)
     : transfer(std::move(transfers)), blk_indices(std::move(blk_indices)), contexts(std::move(level_contexts))
   {}
-  void prolongate(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src) const
+  void prolongate(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    axpby(0.0, dst, 0.0, dst);
-    prolongate_and_add(to_level, dst, src);
+    axpby(0.0, dst, 0.0, dst, stream);
+    prolongate_and_add(to_level, dst, src, stream);
   }
-  void prolongate_and_add(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[to_level].prolongate_and_add(dst, src); }
-  void restrict_and_add(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[from_level].restrict_and_add(dst, src); }
-  void interpolate(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src) const { transfer[from_level].interpolate(dst, src); }
+  void prolongate_and_add(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    transfer[to_level].prolongate_and_add(dst, src, stream);
+  }
+  void restrict_and_add(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    transfer[from_level].restrict_and_add(dst, src, stream);
+  }
+  void interpolate(unsigned from_level, BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    transfer[from_level].interpolate(dst, src, stream);
+  }
   // copy_to_mg (stmg.h:401-415): every level vector sized and zeroed, the finest takes src
-  template <typename Number2> void copy_to_mg(std::vector<BlockVectorType> &dst, const BlockVectorT<Number2> &src) const
+  template <typename Number2> void copy_to_mg(std::vector<BlockVectorType> &dst, const BlockVectorT<Number2> &src, void *stream = nullptr) const
   {
     dst.resize(blk_indices.size());
-    for (size_t l = 0; l < dst.size(); ++l) {
+    for (size_t l = 0; l < dst.size(); ++l)
       if (!dst[l].handle() || dst[l].n_blocks() != blk_indices[l].n_blocks()) dst[l].reinit(contexts[l], blk_indices[l].n_blocks());
-      else if (l + 1 < dst.size()) axpby(0.0, dst[l], 0.0, dst[l]);
-    }
-    check(stfem_vector_convert(dst.back().handle(), src.handle(), nullptr), "copy_to_mg"); // copy_locally_owned_data_from
+    check(stfem_vector_convert(dst.back().handle(), src.handle(), stream), "copy_to_mg"); // copy_locally_owned_data_from
+  }
+  // the zeroing of the coarser level vectors (initialize_dof_vector without omit_zeroing_entries, stmg.h:408-412)
+  void zero_coarser(std::vector<BlockVectorType> &dst, void *stream = nullptr) const
+  {
+    for (size_t l = 0; l + 1 < dst.size(); ++l) axpby(0.0, dst[l], 0.0, dst[l], stream);
   }
   unsigned n_levels() const { return unsigned(blk_indices.size()); }
   const BlockSlice &blk(unsigned l) const { return blk_indices[l]; }
@@ -311,10 +329,10 @@ public:
     keep = vanka;
     omega = relaxation;
   }
-  void vmult(BlockVectorType &dst, const BlockVectorType &src) const
+  void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    if (relax) relax->vmult(dst, src);
-    else axpby(1.0, src, 0.0, dst);
+    if (relax) relax->vmult(dst, src, stream);
+    else axpby(1.0, src, 0.0, dst, stream);
   }
   void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
   bool is_identity() const { return !relax; }
@@ -380,6 +398,9 @@ public:
     defect.clear();
     solution.clear();
     t.clear();
+    d_.clear();
+    graph_.reset();
+    cycles_run = 0;
   }
 
   // PreconditionMG::vmult.  Vectors of another Number (the solver's double against the multigrid's float, stmg.h:1330-1343)
@@ -403,14 +424,14 @@ private:
     BlockVectorType &r = t[level], &d = d_[level];
     unsigned i = 0;
     if (from_zero) {
-      mg_smoother[level].vmult(u, rhs);
+      mg_smoother[level].vmult(u, rhs, stream_);
       i = 1;
     }
     for (; i < steps; ++i) {
-      mg_operators[level]->vmult(r, u);
-      axpby(1.0, rhs, -1.0, r);
-      mg_smoother[level].vmult(d, r);
-      axpby(1.0, d, 1.0, u);
+      mg_operators[level]->vmult(r, u, stream_);
+      axpby(1.0, rhs, -1.0, r, stream_);
+      mg_smoother[level].vmult(d, r, stream_);
+      axpby(1.0, d, 1.0, u, stream_);
     }
   }
   // Multigrid::level_v_step
@@ -421,17 +442,24 @@ private:
       return;
     }
     smooth(level, solution[level], defect[level], true);
-    mg_operators[level]->vmult(t[level], solution[level]);
-    axpby(1.0, defect[level], -1.0, t[level]);
-    transfer_block->restrict_and_add(level, defect[level - 1], t[level]);
+    mg_operators[level]->vmult(t[level], solution[level], stream_);
+    axpby(1.0, defect[level], -1.0, t[level], stream_);
+    transfer_block->restrict_and_add(level, defect[level - 1], t[level], stream_);
     level_v_step(level - 1);
-    transfer_block->prolongate(level, t[level], solution[level - 1]);
-    axpby(1.0, t[level], 1.0, solution[level]);
+    transfer_block->prolongate(level, t[level], solution[level - 1], stream_);
+    axpby(1.0, t[level], 1.0, solution[level], stream_);
     smooth(level, solution[level], defect[level], false);
   }
+  // One cycle = a fixed sequence of ~10^3 launches on the level vectors this object owns.  With STFEM_MG_GRAPH=1 the first
+  // call runs it as it is (the operators allocate their scratch on first use), the second records it into a hipGraph
+  // (stfem_graph_*), every later call replays the graph; only the copies between the caller's vectors and the finest level
+  // vectors stay outside.  Off by default: measured on the cfg-1 mesh (profiles/r2/stmg/driver.txt) the replay takes 21.7 ms per
+  // FGMRES iteration against 20.9 ms of plain launches - the small kernels of the coarse levels (>= 17 us each) are bound by
+  // their own dependent-load chains, the launches already overlap them.
   template <typename Number2> void cycle(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const
   {
-    transfer_block->copy_to_mg(defect, src);
+    if (!stream_ && use_graph) check(stfem_stream_create(&stream_), "stfem_stream_create");
+    transfer_block->copy_to_mg(defect, src, stream_);
     const unsigned n_levels = transfer_block->n_levels();
     if (solution.size() != n_levels) {
       solution.resize(n_levels);
@@ -443,8 +471,31 @@ private:
         d_[l].reinit(transfer_block->context(l), transfer_block->blk(l).n_blocks());
       }
     }
-    level_v_step(n_levels - 1);
-    check(stfem_vector_convert(dst.handle(), solution.back().handle(), nullptr), "copy_from_mg");
+    auto body = [&] {
+      transfer_block->zero_coarser(defect, stream_);
+      level_v_step(n_levels - 1);
+    };
+    if (graph_) {
+      check(stfem_graph_launch(graph_.get(), stream_), "stfem_graph_launch");
+    } else if (use_graph && cycles_run >= 1) {
+      check(stfem_graph_begin(stream_), "stfem_graph_begin");
+      stfem_graph *g = nullptr;
+      try {
+        body();
+      } catch (...) {
+        (void)stfem_graph_end(stream_, &g);
+        stfem_graph_destroy(g);
+        throw;
+      }
+      const int rc = stfem_graph_end(stream_, &g);
+      if (rc != STFEM_OK) throw Error(rc, std::string("stfem_graph_end: ") + stfem_transfer_last_error());
+      graph_.reset(g, stfem_graph_destroy);
+      check(stfem_graph_launch(graph_.get(), stream_), "stfem_graph_launch");
+    } else {
+      body();
+    }
+    ++cycles_run;
+    check(stfem_vector_convert(dst.handle(), solution.back().handle(), stream_), "copy_from_mg");
   }
 
   PreconditionerGMGAdditionalData additional_data;
@@ -455,6 +506,13 @@ private:
   std::unique_ptr<STMGTransferBlockMatrixFree<Number>> transfer_block;
   std::vector<PreconditionSTMG<Number, LevelMatrixType>> mg_smoother;
   mutable std::vector<BlockVectorType> defect, solution, t, d_;
+  mutable void *stream_ = nullptr; // (not destroyed: the object lives as long as the solver)
+  mutable std::shared_ptr<stfem_graph> graph_;
+  mutable unsigned cycles_run = 0;
+  bool use_graph = [] {
+    const char *e = std::getenv("STFEM_MG_GRAPH");
+    return e && std::atoi(e) != 0;
+  }();
 };
 
 // The level hierarchy as tests/tp_01.cc:170-330 sets it up: one mesh per h level (every second vertex plane of the

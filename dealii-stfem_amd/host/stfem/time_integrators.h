@@ -16,9 +16,9 @@
 namespace stfem {
 
 // ---- vector arithmetic of the solver (LinearAlgebra::distributed::BlockVector::add / sadd / equ / l2_norm)
-template <typename Number> void axpby(double a, const BlockVectorT<Number> &x, double b, BlockVectorT<Number> &y)
+template <typename Number> void axpby(double a, const BlockVectorT<Number> &x, double b, BlockVectorT<Number> &y, void *stream = nullptr)
 {
-  check(stfem_vector_axpby(x.context()->h, a, x.handle(), b, y.handle(), nullptr), "stfem_vector_axpby");
+  check(stfem_vector_axpby(x.context()->h, a, x.handle(), b, y.handle(), stream), "stfem_vector_axpby");
 }
 template <typename Number> double norm(const BlockVectorT<Number> &x) { return std::sqrt(dot(x, x)); }
 
@@ -67,19 +67,19 @@ public:
   PreconditionRelaxation(const Operator &A, const PreconditionVanka<Number> &P, double omega, unsigned n_iterations)
     : A(A), P(P), omega(omega), n_iterations(n_iterations)
   {}
-  void vmult(BlockVectorT<Number> &dst, const BlockVectorT<Number> &src) const
+  void vmult(BlockVectorT<Number> &dst, const BlockVectorT<Number> &src, void *stream = nullptr) const
   {
     if (!tmp.handle()) {
       A.initialize_dof_vector(tmp);
       A.initialize_dof_vector(res);
     }
-    P.vmult(dst, src);
-    axpby(0.0, dst, omega, dst);
+    P.vmult(dst, src, stream);
+    axpby(0.0, dst, omega, dst, stream);
     for (unsigned it = 1; it < n_iterations; ++it) {
-      A.vmult(res, dst);
-      axpby(1.0, src, -1.0, res); // res = src - A dst
-      P.vmult(tmp, res);
-      axpby(omega, tmp, 1.0, dst);
+      A.vmult(res, dst, stream);
+      axpby(1.0, src, -1.0, res, stream); // res = src - A dst
+      P.vmult(tmp, res, stream);
+      axpby(omega, tmp, 1.0, dst, stream);
     }
   }
 

@@ -51,7 +51,16 @@ template <typename NP> int run(int argc, char **argv)
     }
   x.copy_from_host(hx);
   A.vmult(src, x); // a right-hand side with zero constrained rows, like every vector FGMRES hands over
-  mg.gmg->vmult(dst, src);
+  mg.gmg->vmult(dst, src); // plain launches
+  // the second application records the cycle into a hipGraph, the third replays it: all three must agree
+  BlockVectorT<NP> dst2, dst3;
+  A.initialize_dof_vector(dst2);
+  A.initialize_dof_vector(dst3);
+  mg.gmg->vmult(dst2, src);
+  mg.gmg->vmult(dst3, src);
+  axpby(-1.0, dst, 1.0, dst2);
+  axpby(-1.0, dst, 1.0, dst3);
+  std::printf("graph: recorded %.3e replayed %.3e of %.3e\n", norm(dst2), norm(dst3), norm(dst));
 
   FILE *f = std::fopen(argv[10], "wb");
   if (!f) return 3;

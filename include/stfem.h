@@ -236,6 +236,22 @@ int stfem_transfer_line_matrices(int ncell_fine, int degree_fine, int ncell_coar
  * (GMG::vmult, stmg.h:1330-1343: the multigrid runs in NumberPreconditioner, the solver in Number) */
 int stfem_vector_convert(stfem_vec *dst, const stfem_vec *src, void *stream);
 
+/* A launch-bound fixed sequence of calls (one multigrid V-cycle is ~1300 kernel launches, most of them on coarse levels)
+ * recorded once and replayed as one hipGraph.  stream_create: a stream of the caller's own (ordered against the default
+ * stream the other entry points use when given NULL).  graph_begin(stream): from here every stfem_* call given this stream
+ * is recorded, not run (calls that allocate or synchronise - vector_create, dot, upload, the first use of an operator on a
+ * context - are not allowed in between: run the sequence once before recording it); graph_end returns the instantiated
+ * graph; graph_launch replays it on `stream` with the vectors (device pointers) it was recorded with.  Errors:
+ * stfem_transfer_last_error. */
+typedef struct stfem_graph stfem_graph;
+int stfem_stream_create(void **stream_out);
+void stfem_stream_destroy(void *stream);
+int stfem_stream_synchronize(void *stream);
+int stfem_graph_begin(void *stream);
+int stfem_graph_end(void *stream, stfem_graph **out);
+int stfem_graph_launch(stfem_graph *g, void *stream);
+void stfem_graph_destroy(stfem_graph *g);
+
 /* Cell-patch Vanka / additive-Schwarz smoother of the space-time system A = Alpha (x) K + Beta (x) M:
  * PreconditionVanka (include/stmg.h:619-907; set-up 786-829 with compute_block_matrix.h:50-139, apply
  * 832-872).  create: builds and inverts the valence-weighted cell blocks of the ASSEMBLED matrices (zero

@@ -144,14 +144,14 @@ def test_vcycle_vs_oracle(ttype, k, n, nsteps, p, ctype, pmg, distort, number, t
         subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     out = tmp_path / "stmg.bin"
     res = subprocess.run([exe, str(ttype), str(k), str(n), str(nsteps), str(p), "1" if ctype == "space_and_time" else "0", "1" if pmg else "0", number,
-                          str(distort), str(out)], capture_output=True, text=True, timeout=600)
+                          str(distort), str(out)], capture_output=True, text=True, timeout=600, env=dict(os.environ, STFEM_MG_GRAPH="1"))
     assert res.returncode == 0, res.stdout + res.stderr
     n_levels, nb, N = (int(x) for x in np.fromfile(out, dtype=np.uint64, count=3))
     flat = np.fromfile(out, dtype=np.float64, offset=24)
     omegas, ids = flat[:n_levels], flat[n_levels:2 * n_levels].astype(int)
     src, dst = flat[2 * n_levels:].reshape(2, nb * N)
     seq, levels, mg = _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distort, omegas, ids)
-    assert res.stdout.split("levels:")[1].split() == list(seq)
+    assert res.stdout.split("levels:")[1].split("\n")[0].split() == list(seq)
     assert len(levels) == n_levels and levels[-1]["nb"] == nb and levels[-1]["N"] == N
     assert list(ids) == stfem.get_precondition_stmg_types(seq, ctype, False)
     # the relaxation parameter the mirror estimated (power iteration as deal.II's PreconditionRelaxation) against the restated estimate
@@ -161,6 +161,9 @@ def test_vcycle_vs_oracle(ttype, k, n, nsteps, p, ctype, pmg, distort, number, t
             assert abs(omegas[l] - want) < (1e-8 if number == "double" else 2e-3) * want, (l, omegas[l], want)
     want = mg.vmult(src)
     assert rel(dst, want) < (1e-9 if number == "double" else 5e-3)
+    # the cycle recorded into a hipGraph and its replay give the result of the plain launches
+    recorded, replayed, size = (float(x) for x in res.stdout.split("graph: recorded")[1].replace("replayed", "").replace("of", "").split())
+    assert recorded <= 1e-14 * size and replayed <= 1e-14 * size, res.stdout
 
 
 @pytest.mark.parametrize("ttype,k,refinement,nsteps,extra", [
