@@ -100,6 +100,24 @@ std::vector<std::array<FullMatrix<Number>, 4>> get_fe_time_weights(TimeStepType 
   return tw;
 }
 
+// fe_time.h:445-476: the wave matrices {Alpha_lhs, Beta_lhs, rhs_uK, rhs_uM, rhs_vM} of every level, finest last
+template <typename Number>
+std::vector<std::array<FullMatrix<Number>, 5>> get_fe_time_weights_wave(TimeStepType type, double time_step_size, unsigned n_timesteps_at_once,
+                                                                        const std::vector<MGType> &mg_type_level,
+                                                                        const std::vector<unsigned> &poly_time_sequence)
+{
+  std::vector<std::array<FullMatrix<Number>, 5>> tw(mg_type_level.size() + 1);
+  auto t = tw.rbegin();
+  auto p_mg = poly_time_sequence.rbegin();
+  *t++ = get_fe_time_weights_wave<Number>(type, *p_mg, time_step_size, n_timesteps_at_once);
+  for (auto mgt = mg_type_level.rbegin(); mgt != mg_type_level.rend(); ++mgt, ++t) {
+    if (*mgt == MGType::k) ++p_mg;
+    else if (*mgt == MGType::tau) n_timesteps_at_once /= 2, time_step_size *= 2;
+    *t = get_fe_time_weights_wave<Number>(type, *p_mg, time_step_size, n_timesteps_at_once);
+  }
+  return tw;
+}
+
 // parameters.h:11-31
 struct PreconditionerGMGAdditionalData {
   double smoothing_range = 1;
@@ -523,7 +541,8 @@ template <int dim, typename Number> struct STMGHierarchy {
   using System = SystemMatrix<dim, Number, Operator>;
   std::vector<MGType> mg_type_level;
   std::vector<unsigned> poly_time_sequence;
-  std::vector<std::array<FullMatrix<Number>, 4>> fetw;
+  std::vector<std::array<FullMatrix<Number>, 4>> fetw;   // heat (tests/tp_01.cc:226-233)
+  std::vector<std::array<FullMatrix<Number>, 5>> fetw_w; // wave (234-241)
   std::vector<std::shared_ptr<Operator>> K, M;
   std::vector<std::shared_ptr<const System>> operators;
   std::vector<std::shared_ptr<PreconditionVanka<Number>>> vanka;
@@ -532,11 +551,13 @@ template <int dim, typename Number> struct STMGHierarchy {
   // poly_space_sequence: spatial degree per p level, coarsest first (used if the schedule holds 'p' transfers)
   STMGHierarchy(const Mesh &fine_mesh, unsigned fe_degree_space, const std::vector<unsigned> &poly_space_sequence, TimeStepType type, double time_step_size,
                 unsigned n_timesteps_at_once, const std::vector<MGType> &mg_type_level_, const std::vector<unsigned> &poly_time_sequence_,
-                const PreconditionerGMGAdditionalData &mg_data, CoarseningType coarsening_type, bool time_before_space, bool space_time_level_first)
+                const PreconditionerGMGAdditionalData &mg_data, CoarseningType coarsening_type, bool time_before_space, bool space_time_level_first,
+                bool wave = false)
     : mg_type_level(mg_type_level_), poly_time_sequence(poly_time_sequence_)
   {
     const unsigned n_levels = unsigned(mg_type_level.size()) + 1;
-    fetw = get_fe_time_weights<Number>(type, time_step_size, n_timesteps_at_once, mg_type_level, poly_time_sequence);
+    if (wave) fetw_w = get_fe_time_weights_wave<Number>(type, time_step_size, n_timesteps_at_once, mg_type_level, poly_time_sequence);
+    else fetw = get_fe_time_weights<Number>(type, time_step_size, n_timesteps_at_once, mg_type_level, poly_time_sequence);
     K.resize(n_levels);
     M.resize(n_levels);
     operators.resize(n_levels);
@@ -558,8 +579,9 @@ template <int dim, typename Number> struct STMGHierarchy {
         K[l] = K[l + 1];
         M[l] = M[l + 1];
       }
-      operators[l] = std::make_shared<const System>(*K[l], *M[l], fetw[l][0], fetw[l][1]);
-      vanka[l] = std::make_shared<PreconditionVanka<Number>>(*K[l], fetw[l][0], fetw[l][1]);
+      const FullMatrix<Number> &lhs_uK = wave ? fetw_w[l][0] : fetw[l][0], &lhs_uM = wave ? fetw_w[l][1] : fetw[l][1]; // tests/tp_01.cc:279-282
+      operators[l] = std::make_shared<const System>(*K[l], *M[l], lhs_uK, lhs_uM);
+      vanka[l] = std::make_shared<PreconditionVanka<Number>>(*K[l], lhs_uK, lhs_uM);
     }
     gmg = std::make_unique<GMG<dim, Number, System>>(mg_data, type, n_timesteps_at_once, mg_type_level, poly_time_sequence, coarsening_type, time_before_space,
                                                      space_time_level_first, operators, vanka);

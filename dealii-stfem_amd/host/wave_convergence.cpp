@@ -8,7 +8,11 @@
 // Usage: wave_convergence <type 0 = cG | 1 = dG> <k> <refinement> <n_timesteps_at_once> [vanka sweeps = 2, 0 = none] [omega = 0.5]
 //                         [fe_degree = k + 1] [cells per direction = 2^refinement] [end_time = 1] [FGMRES steps = 200]
 // Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
+#include "stfem/stmg.h"
 #include "stfem/time_integrators.h"
+
+#include <cstring>
+#include <map>
 
 #include <cstdio>
 #include <cstdlib>
@@ -16,8 +20,19 @@
 using namespace stfem;
 using Number = double;
 
-int main(int argc, char **argv)
+int main(int argc_all, char **argv_all)
 {
+  // key=value options as in heat_convergence: mg=1 (space-time multigrid as preconditioner), mg_float=1, coarsening=..., pmg=1, kmin=, relaxation=, variable=, steps=
+  std::map<std::string, std::string> opt;
+  std::vector<char *> pos;
+  for (int i = 0; i < argc_all; ++i) {
+    const char *eq = std::strchr(argv_all[i], '=');
+    if (i > 0 && eq) opt[std::string(argv_all[i], size_t(eq - argv_all[i]))] = eq + 1;
+    else pos.push_back(argv_all[i]);
+  }
+  const int argc = int(pos.size());
+  char **argv = pos.data();
+  auto option = [&](const char *key, const char *dflt) { return opt.count(key) ? opt[key] : std::string(dflt); };
   if (argc < 5) {
     std::fprintf(stderr, "usage: %s type k refinement n_timesteps_at_once [sweeps] [omega]\n", argv[0]);
     return 2;
@@ -97,7 +112,34 @@ int main(int argc, char **argv)
         time += nsteps * tau;
       }
     };
-    if (sweeps > 0) {
+    if (option("mg", "0") == "1") { // tests/tp_01.cc:170-344 with ProblemType::wave
+      unsigned n_sp_lvl = 1;
+      for (int c = n; c % 2 == 0; c /= 2) ++n_sp_lvl;
+      const unsigned kmin = std::min<unsigned>(k, std::atoi(option("kmin", "1").c_str()));
+      const auto poly_time = get_poly_mg_sequence(k, kmin, PolynomialCoarseningSequenceType::bisect);
+      std::vector<unsigned> poly_space;
+      for (unsigned q : poly_time) poly_space.push_back(q + (fe_degree - k));
+      const bool use_pmg = option("pmg", "0") == "1";
+      const auto ctype = option("coarsening", "space_or_time") == "space_and_time" ? CoarseningType::space_and_time : CoarseningType::space_or_time;
+      const auto mg_type_level = get_mg_sequence(n_sp_lvl, poly_time, poly_space, nsteps, 1, MGType::tau, ctype, false, use_pmg, true);
+      PreconditionerGMGAdditionalData mg_data;
+      mg_data.relaxation = std::atof(option("relaxation", "0").c_str());
+      mg_data.variable = option("variable", "1") == "1";
+      mg_data.smoothing_steps = std::atoi(option("steps", "1").c_str());
+      std::fprintf(stderr, "levels:");
+      for (auto m : mg_type_level) std::fprintf(stderr, " %c", char(m));
+      std::fprintf(stderr, "\n");
+      auto with = [&](auto number_tag) {
+        using NP = decltype(number_tag);
+        STMGHierarchy<3, NP> mg(mesh, fe_degree, poly_space, type, tau, nsteps, mg_type_level, poly_time, mg_data, ctype, false, true, /*wave*/ true);
+        using P = GMG<3, NP, typename STMGHierarchy<3, NP>::System>;
+        TimeIntegratorWave<Number, SystemN, SystemN, P> step(type, k, Alpha_1, Beta_1, Gamma_1, Zeta_1, 1e-12, matrix, *mg.gmg, rhs_matrix, rhs_matrix_v, source,
+                                                             nsteps, true, max_steps);
+        run(step);
+      };
+      if (option("mg_float", "0") == "1") with(float());
+      else with(double());
+    } else if (sweeps > 0) {
       PreconditionVanka<Number> vanka(K_mf, Alpha, Beta);
       PreconditionRelaxation<Number, SystemN> precond(matrix, vanka, omega, sweeps);
       TimeIntegratorWave<Number, SystemN, SystemN, decltype(precond)> step(type, k, Alpha_1, Beta_1, Gamma_1, Zeta_1, 1e-12, matrix, precond, rhs_matrix,

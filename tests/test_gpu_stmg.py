@@ -183,3 +183,21 @@ def test_heat_driver_with_stmg(ttype, k, refinement, nsteps, extra):
     got = np.array([float(l8), float(l2), float(h1)])
     assert np.allclose(got, np.array(want), rtol=1e-7, atol=1e-10), (got, want)
     assert float(its) <= 30, res.stderr
+
+
+@pytest.mark.parametrize("ttype,k,refinement,nsteps,extra", [
+    (0, 1, 2, 2, []),               # cG(1), Q2: levels h h t with the wave matrices of fe_time.h:157-305 on every level
+    (1, 1, 1, 2, ["mg_float=1"]),   # dG(1)
+])
+def test_wave_driver_with_stmg(ttype, k, refinement, nsteps, extra):
+    from oracle import slab_oracle
+    exe = os.path.join(HOST, "wave_convergence")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    res = subprocess.run([exe, str(ttype), str(k), str(refinement), str(nsteps), "mg=1", *extra], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    cells, sdofs, tdofs, l8, l2, h1, its = res.stdout.split()
+    want = slab_oracle.wave_convergence_row_3d(ttype, k, refinement, nsteps)
+    got = np.array([float(l8), float(l2), float(h1)])
+    assert np.allclose(got, np.array(want), rtol=1e-7, atol=1e-10), (got, want)
+    assert float(its) <= 30, res.stderr
