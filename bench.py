@@ -352,7 +352,12 @@ def main():
                        "local_sweep_ms": kms, "exchange_ms": xms,
                        "exchange": None if world == 1 else
                        ("RCCL behind the C-ABI (stfem_halo_begin/end)" if comm is not None
-                        else f"torch.distributed ({args.backend}) P2P around stfem_plane_pack/unpack")},
+                        else f"torch.distributed ({args.backend}) P2P around stfem_plane_pack/unpack"),
+                       # the default N = 1 line is configs[1] (Cartesian mesh, fast-diagonalisation kernel); N > 1 defaults to the
+                       # configs[2] mesh type (general-geometry kernel, ~4x the time per cell): the one-GPU point of THIS curve is
+                       # `bench.py --gpus 1 --distort 0.15` (weak) or `--gpus 1 --scaling strong --distort 0.15` (strong)
+                       "one_gpu_point_of_this_curve": None if world == 1 else
+                       ("bench.py --gpus 1 --distort %g" % args.distort + (" --scaling strong" if args.scaling == "strong" else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
