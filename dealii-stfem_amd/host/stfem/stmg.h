@@ -304,9 +304,20 @@ private:
 
 // The largest eigenvalue of P^-1 A by deal.II's power iteration (what PreconditionRelaxation does when its
 // relaxation parameter is 0, as the reference leaves it: parameters.h:19, stmg.h:1207-1213): start vector
-// (i mod 11) - mean on every block, n_iterations steps; relaxation = 2 / (0.9 lambda + lambda) for smoothing_range <= 1
+// (i mod 11) - mean on every block, n_iterations steps; relaxation = 2 / (alpha + 1.2 lambda), alpha = min(1.08 lambda, 1) for
+// smoothing_range <= 1 (restated from deal.II's documentation of PreconditionRelaxation / PreconditionChebyshev; not checked against a build)
+template <typename Number, typename Operator, typename Precond> double estimate_max_eigenvalue(const Operator &A, const Precond &P, unsigned n_iterations);
 template <typename Number, typename Operator, typename Precond>
 double estimate_relaxation(const Operator &A, const Precond &P, unsigned n_iterations, double smoothing_range)
+{
+  const double lambda = estimate_max_eigenvalue<Number>(A, P, n_iterations);
+  if (!(lambda > 0) || !std::isfinite(lambda)) return 1.0; // a level without free DoFs (one Q1 cell, all nodes constrained): nothing to relax
+  // internal::PreconditionChebyshevImplementation::estimate_eigenvalues with the power iteration: the tracker holds {1, lambda}, i.e. the
+  // lower estimate is 1 and the upper one carries the safety factor 1.2
+  const double beta = 1.2 * lambda, alpha = smoothing_range > 1.0 ? beta / smoothing_range : std::min(0.9 * beta, 1.0);
+  return 2.0 / (alpha + beta);
+}
+template <typename Number, typename Operator, typename Precond> double estimate_max_eigenvalue(const Operator &A, const Precond &P, unsigned n_iterations)
 {
   BlockVectorT<Number> v, w, z;
   A.initialize_dof_vector(v);
@@ -329,14 +340,62 @@ double estimate_relaxation(const Operator &A, const Precond &P, unsigned n_itera
     if (!(nw > 0)) break;
     axpby(1.0 / nw, w, 0.0, v);
   }
-  lambda = std::abs(lambda);
-  if (!(lambda > 0) || !std::isfinite(lambda)) return 1.0; // a level without free DoFs (one Q1 cell, all nodes constrained): nothing to relax
-  const double alpha = smoothing_range > 1.0 ? lambda / smoothing_range : 0.9 * lambda;
-  return 2.0 / (alpha + lambda);
+  return std::abs(lambda);
 }
 
+// deal.II PreconditionChebyshev<LevelMatrix, BlockVector, PreconditionVanka> as the reference's second smoother alternative
+// sets it up (stmg.h:1216-1227: degree = smoothing_steps, power iteration for the largest eigenvalue of P^-1 A, smoothing_range):
+// Chebyshev iteration on [alpha, 1.2 lambda] from x = 0, `degree` applications of P^-1 (the first without a matrix product):
+//   x_1 = P^-1 b / theta;   x_{k+1} = x_k + rho_{k+1} rho_k (x_k - x_{k-1}) + 2 rho_{k+1} / delta P^-1 (b - A x_k),
+//   theta = (beta + alpha) / 2, delta = (beta - alpha) / 2, sigma = theta / delta, rho_1 = 1 / sigma, rho_{k+1} = 1 / (2 sigma - rho_k)
+template <typename Number, typename Operator> class PreconditionChebyshev {
+public:
+  PreconditionChebyshev(const Operator &A, const PreconditionVanka<Number> &P, double lambda_max, double smoothing_range, unsigned degree)
+    : A(A), P(P), degree(degree)
+  {
+    const double beta = 1.2 * lambda_max; // deal.II's safety factor on the estimate; the lower estimate of the power iteration is 1
+    const double alpha = smoothing_range > 1.0 ? beta / smoothing_range : std::min(0.9 * beta, 1.0);
+    theta = 0.5 * (beta + alpha);
+    delta = 0.5 * (beta - alpha);
+  }
+  void vmult(BlockVectorT<Number> &dst, const BlockVectorT<Number> &src, void *stream = nullptr) const
+  {
+    if (!tmp.handle()) {
+      A.initialize_dof_vector(tmp);
+      A.initialize_dof_vector(res);
+      A.initialize_dof_vector(old);
+    }
+    P.vmult(dst, src, stream);
+    axpby(0.0, dst, 1.0 / theta, dst, stream); // x_1
+    if (degree < 2) return;
+    axpby(0.0, old, 0.0, old, stream);          // x_0 = 0
+    const double sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    for (unsigned k = 1; k < degree; ++k) {
+      const double rho_new = 1.0 / (2.0 * sigma - rho), f1 = rho_new * rho, f2 = 2.0 * rho_new / delta;
+      A.vmult(res, dst, stream);
+      axpby(1.0, src, -1.0, res, stream); // res = b - A x_k
+      P.vmult(tmp, res, stream);
+      // old <- x_k + f1 (x_k - old) + f2 tmp, then swap the roles of old and dst
+      axpby(1.0 + f1, dst, -f1, old, stream);
+      axpby(f2, tmp, 1.0, old, stream);
+      axpby(1.0, dst, 0.0, tmp, stream); // tmp = x_k
+      axpby(1.0, old, 0.0, dst, stream); // dst = x_{k+1}
+      axpby(1.0, tmp, 0.0, old, stream); // old = x_k
+      rho = rho_new;
+    }
+  }
+
+private:
+  const Operator &A;
+  const PreconditionVanka<Number> &P;
+  unsigned degree;
+  double theta = 1.0, delta = 1.0;
+  mutable BlockVectorT<Number> tmp, res, old;
+};
+
 // stmg.h:968-1045 PreconditionSTMG: the smoother of one level - identity, or relaxation sweeps of the Vanka smoother
-// (PreconditionChebyshev, the third alternative of the reference, is not built)
+// or the Chebyshev iteration around it
 template <typename Number, typename LevelMatrixType> class PreconditionSTMG {
 public:
   using BlockVectorType = BlockVectorT<Number>;
@@ -347,17 +406,26 @@ public:
     keep = vanka;
     omega = relaxation;
   }
+  void initialize_chebyshev(const LevelMatrixType &matrix, const std::shared_ptr<PreconditionVanka<Number>> &vanka, double lambda_max, double smoothing_range,
+                            unsigned degree)
+  {
+    cheb = std::make_unique<PreconditionChebyshev<Number, LevelMatrixType>>(matrix, *vanka, lambda_max, smoothing_range, degree);
+    keep = vanka;
+    omega = lambda_max;
+  }
   void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
     if (relax) relax->vmult(dst, src, stream);
+    else if (cheb) cheb->vmult(dst, src, stream);
     else axpby(1.0, src, 0.0, dst, stream);
   }
   void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
-  bool is_identity() const { return !relax; }
+  bool is_identity() const { return !relax && !cheb; }
   double relaxation() const { return omega; }
 
 private:
   std::unique_ptr<PreconditionRelaxation<Number, LevelMatrixType>> relax;
+  std::unique_ptr<PreconditionChebyshev<Number, LevelMatrixType>> cheb;
   std::shared_ptr<PreconditionVanka<Number>> keep;
   double omega = 1.0;
 };
@@ -378,7 +446,6 @@ public:
   {
     const unsigned n_levels = unsigned(mg_operators.size());
     if (additional_data.coarse_grid_smoother_type != "Smoother") throw std::invalid_argument("GMG: only the smoother as coarse solver is built");
-    if (additional_data.smoother == SupportedSmoothers::Chebyshev) throw std::invalid_argument("GMG: the Chebyshev smoother is not built");
     std::vector<BlockSlice> blk_indices = get_blk_indices(type, n_timesteps_at_once, 1u, n_levels, mg_type_level, poly_time_sequence);
     // build_stmg_transfers (stmg.h:503-617)
     std::vector<std::shared_ptr<Context>> contexts(n_levels);
@@ -407,6 +474,12 @@ public:
     mg_smoother.resize(n_levels);
     for (unsigned l = 0; l < n_levels; ++l) {
       if (precondition_sequence[l] == unsigned(SupportedSmoothers::Identity)) continue;
+      if (precondition_sequence[l] == unsigned(SupportedSmoothers::Chebyshev)) { // stmg.h:1216-1227
+        const double lambda = estimate_max_eigenvalue<Number>(*mg_operators[l], *precondition_vanka[l], additional_data.smoothing_eig_cg_n_iterations);
+        mg_smoother[l].initialize_chebyshev(*mg_operators[l], precondition_vanka[l], lambda > 0 && std::isfinite(lambda) ? lambda : 1.0,
+                                            additional_data.smoothing_range, additional_data.smoothing_steps);
+        continue;
+      }
       double omega = additional_data.relaxation;
       if (omega == 0.0)
         omega = estimate_relaxation<Number>(*mg_operators[l], *precondition_vanka[l], additional_data.smoothing_eig_cg_n_iterations,

@@ -139,9 +139,8 @@ def time_transfer(ttype, kind, r_hi, r_lo, n_hi, restrict_is_transpose_prolongat
     return P, (P.T.copy() if restrict_is_transpose_prolongate else down)
 
 
-def power_iteration_relaxation(A, Pinv, nb, n, n_iterations=20, smoothing_range=1.0):
-    """deal.II PreconditionRelaxation with relaxation = 0: largest eigenvalue of P^-1 A by power iteration from the
-    vector (i mod 11) - mean on every block; relaxation = 2 / (0.9 lambda + lambda)"""
+def power_iteration(A, Pinv, nb, n, n_iterations=20):
+    """largest eigenvalue of P^-1 A by deal.II's power iteration from the vector (i mod 11) - mean on every block"""
     g = np.arange(n) % 11
     g = g - g.mean()
     v = np.tile(g, nb).astype(float)
@@ -153,11 +152,23 @@ def power_iteration_relaxation(A, Pinv, nb, n, n_iterations=20, smoothing_range=
         if not np.linalg.norm(w) > 0:
             break
         v = w / np.linalg.norm(w)
-    lam = abs(lam)
+    return abs(lam)
+
+
+def chebyshev_interval(lam, smoothing_range=1.0):
+    """(alpha, beta) as deal.II derives them from the power iteration: upper estimate 1.2 lambda, lower estimate 1"""
+    beta = 1.2 * lam
+    alpha = beta / smoothing_range if smoothing_range > 1 else min(0.9 * beta, 1.0)
+    return alpha, beta
+
+
+def power_iteration_relaxation(A, Pinv, nb, n, n_iterations=20, smoothing_range=1.0):
+    """deal.II PreconditionRelaxation with relaxation = 0: 2 / (alpha + beta)"""
+    lam = power_iteration(A, Pinv, nb, n, n_iterations)
     if not lam > 0:  # a level without free DoFs
         return 1.0
-    alpha = lam / smoothing_range if smoothing_range > 1 else 0.9 * lam
-    return 2.0 / (alpha + lam)
+    alpha, beta = chebyshev_interval(lam, smoothing_range)
+    return 2.0 / (alpha + beta)
 
 
 class Multigrid:
@@ -172,6 +183,17 @@ class Multigrid:
         lv = self.levels[l]
         if lv["smoother"] is None:  # PreconditionIdentity
             return r.copy()
+        if lv.get("chebyshev"):  # PreconditionChebyshev: `degree` applications of P^-1 on [alpha, beta], from 0
+            alpha, beta = lv["chebyshev"]
+            theta, delta = 0.5 * (beta + alpha), 0.5 * (beta - alpha)
+            x_old, x = np.zeros_like(r), lv["smoother"](r) / theta
+            sigma = theta / delta
+            rho = 1.0 / sigma
+            for _ in range(1, lv["n_iterations"]):
+                rho_new = 1.0 / (2.0 * sigma - rho)
+                x, x_old = x + rho_new * rho * (x - x_old) + 2.0 * rho_new / delta * lv["smoother"](r - lv["A"] @ x), x
+                rho = rho_new
+            return x
         # PreconditionRelaxation: n_iterations sweeps from 0
         x = lv["omega"] * lv["smoother"](r)
         for _ in range(1, lv["n_iterations"]):

@@ -75,7 +75,7 @@ def test_vector_convert():
     assert np.array_equal(vc.download(), X.astype(np.float32).astype(float))
 
 
-def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distort, omegas, ids, variable=True):
+def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distort, omegas, ids, variable=True, steps=1):
     """the hierarchy of host/test_host_stmg.cpp rebuilt from the restatement"""
     from oracle import stmg_oracle, vanka_oracle
     tau = 0.0625
@@ -115,7 +115,9 @@ def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distor
             continue
         van = vanka_oracle.VankaOracle(deg, nc, verts, 63, Alpha, Beta)
         sm = lambda v, van=van, nb=nb, N=N: van.vmult(v.reshape(nb, N)).ravel()  # noqa: E731
-        levels.append(dict(A=A, smoother=sm, omega=omegas[l], n_iterations=1, nb=nb, N=N))
+        levels.append(dict(A=A, smoother=sm, omega=omegas[l], n_iterations=steps, nb=nb, N=N))
+        if ids[l] == 2:  # Chebyshev: the file holds the eigenvalue estimate
+            levels[-1]["chebyshev"] = stmg_oracle.chebyshev_interval(omegas[l])
     for l in range(1, n_levels):
         kind = seq[l - 1]
         if kind in "hp":
@@ -164,6 +166,29 @@ def test_vcycle_vs_oracle(ttype, k, n, nsteps, p, ctype, pmg, distort, number, t
     # the cycle recorded into a hipGraph and its replay give the result of the plain launches
     recorded, replayed, size = (float(x) for x in res.stdout.split("graph: recorded")[1].replace("replayed", "").replace("of", "").split())
     assert recorded <= 1e-14 * size and replayed <= 1e-14 * size, res.stdout
+
+
+@pytest.mark.parametrize("number", ["double", "float"])
+def test_vcycle_chebyshev_vs_oracle(number, tmp_path, oracle_mod):
+    """the reference's second smoother (SupportedSmoothers::Chebyshev, stmg.h:1216-1227): degree-3 Chebyshev iteration around the Vanka apply"""
+    from oracle import stmg_oracle
+    stfem = importlib.import_module("dealii-stfem_amd")
+    ttype, k, n, nsteps, p, ctype = 0, 2, 4, 1, 2, "space_or_time"
+    exe = os.path.join(HOST, "test_host_stmg")
+    out = tmp_path / "stmg.bin"
+    res = subprocess.run([exe, str(ttype), str(k), str(n), str(nsteps), str(p), "0", "0", number, "0.0", str(out), "0", "0", "2", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    n_levels, nb, N = (int(x) for x in np.fromfile(out, dtype=np.uint64, count=3))
+    flat = np.fromfile(out, dtype=np.float64, offset=24)
+    lambdas, ids = flat[:n_levels], flat[n_levels:2 * n_levels].astype(int)
+    assert set(ids) == {2}
+    src, dst = flat[2 * n_levels:].reshape(2, nb * N)
+    seq, levels, mg = _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, False, 0.0, lambdas, ids, variable=False, steps=3)
+    for l, lv in enumerate(levels):
+        want = stmg_oracle.power_iteration(lv["A"], lv["smoother"], lv["nb"], lv["N"])
+        assert abs(lambdas[l] - want) < (1e-8 if number == "double" else 2e-3) * want
+    assert rel(dst, mg.vmult(src)) < (1e-9 if number == "double" else 5e-3)
 
 
 @pytest.mark.parametrize("ttype,k,refinement,nsteps,extra", [
