@@ -60,6 +60,27 @@ def test_bad_arguments_are_reported(stfem):
     assert b"invalid" in L.stfem_strerror(-1)
 
 
+def test_multigrid_entry_points_reject_bad_arguments(stfem):
+    """the f-2 entry points: argument errors are status codes, nothing throws or faults without a GPU"""
+    L = stfem.lib()
+    n = C.c_int32(0)
+    assert L.stfem_poly_mg_sequence(1, 2, 0, None, C.byref(n)) == -1          # k_max < k_min
+    assert L.stfem_poly_mg_sequence(4, 1, 9, None, C.byref(n)) == -1          # unknown coarsening sequence
+    assert L.stfem_mg_sequence(0, 1, 0, 1, 1, b"k", 1, 0, 0, 1, None, C.byref(n)) == -1   # no space level
+    assert L.stfem_mg_sequence(1, 1, 0, 1, 1, b"x", 1, 0, 0, 1, None, C.byref(n)) == -1   # lower level neither k nor tau
+    assert L.stfem_mg_sequence(1, 2, 0, 1, 1, b"k", 1, 0, 1, 1, None, C.byref(n)) == -1   # p-multigrid without a degree sequence
+    dims = (C.c_int32 * 2)()
+    assert L.stfem_time_prolongation_matrix(0, 2, 3, None, dims) < 0           # steps per slab not a power of two
+    assert L.stfem_time_projection_matrix(0, 0, 1, 1, None, dims) < 0          # cG(0) does not exist
+    assert L.stfem_transfer_create(None, None, None) == -1
+    assert L.stfem_transfer_prolongate(None, None, None, 0, None) == -1
+    assert L.stfem_transfer_line_matrices(3, 2, 2, 2, None, None) == -1        # 3 fine cells on 2 coarse ones
+    assert L.stfem_transfer_line_matrices(4, 1, 2, 2, None, None) == -1        # fine degree below the coarse one
+    assert L.stfem_vector_convert(None, None, None) == -1
+    assert L.stfem_graph_begin(None) == -1                                     # the default stream cannot be captured
+    assert L.stfem_graph_launch(None, None) == -1
+
+
 def test_mesh_vertices(stfem):
     gn = (4, 3, 6)
     full = stfem.mesh_vertices(gn, (0, 0, 0), (1, 2, 3), distort=0.15, seed=5489)
