@@ -111,3 +111,34 @@ def test_cfg3_wave_q3_dg2_discontinuous_coefficient(stfem):
     ctx1 = stfem.MatrixFreeOperator(p, nc, lower=lo, upper=up)
     K1X = st_apply(stfem, ctx1, I3, Z3, X)
     assert 1.0 < np.vdot(X, KX) / np.vdot(X, K1X) < 16.0
+
+
+def test_cfg1_mesh_space_transfers_properties(stfem):
+    """f-2 at the size of configs[1] (72^3 -> 36^3 cells, Q4; then Q4 -> Q2 on 72^3): properties instead of the oracle"""
+    rng = np.random.default_rng(5)
+    for (pf, ncf, pc, ncc) in ((4, (72, 72, 72), 4, (36, 36, 36)), (4, (72, 72, 72), 2, (72, 72, 72))):
+        for mask in (0, 63):
+            fine = stfem.MatrixFreeOperator(pf, ncf, dirichlet_mask=mask)
+            coarse = stfem.MatrixFreeOperator(pc, ncc, dirichlet_mask=mask)
+            T = stfem.MGTwoLevelTransfer(fine, coarse)
+            Uc = rng.uniform(-1, 1, (1, coarse.n_dofs))
+            Vf = rng.uniform(-1, 1, (1, fine.n_dofs))
+            if mask:  # vectors of the constrained spaces
+                nf, nc_ = [pf * c + 1 for c in ncf], [pc * c + 1 for c in ncc]
+                g = Vf.reshape(nf[2], nf[1], nf[0]); g[0] = g[-1] = 0; g[:, 0] = g[:, -1] = 0; g[:, :, 0] = g[:, :, -1] = 0
+                g = Uc.reshape(nc_[2], nc_[1], nc_[0]); g[0] = g[-1] = 0; g[:, 0] = g[:, -1] = 0; g[:, :, 0] = g[:, :, -1] = 0
+            uc, vf = stfem.BlockVector(coarse, 1).upload(Uc), stfem.BlockVector(fine, 1).upload(Vf)
+            pu, rv, ipu = stfem.BlockVector(fine, 1), stfem.BlockVector(coarse, 1), stfem.BlockVector(coarse, 1)
+            T.prolongate(pu, uc)
+            T.restrict_and_add(rv, vf)
+            # restriction is the transpose of the prolongation
+            a, b = stfem.dot(fine, pu, vf), stfem.dot(coarse, uc, rv)
+            assert abs(a - b) < 1e-12 * max(abs(a), 1.0), (a, b)
+            # the nodal interpolation is a left inverse of the embedding
+            T.interpolate(ipu, pu)
+            assert rel(ipu.download(), Uc) < 1e-13
+            if mask == 0:  # constants are reproduced
+                one_c = stfem.BlockVector(coarse, 1).upload(np.ones((1, coarse.n_dofs)))
+                T.prolongate(pu, one_c)
+                assert np.abs(pu.download() - 1.0).max() < 1e-13
+            del T, uc, vf, pu, rv, ipu, fine, coarse
