@@ -299,6 +299,148 @@ __global__ __launch_bounds__(256) void vanka_apply_percell_kernel(const VankaCel
   }
 }
 
+
+// ---- device-side set-up of the per-cell blocks (large general meshes: MI355X holds the reference's one-block-per-cell layout of
+// a whole configs[2] / configs[3] mesh in HBM; the set-up must then not go through the host either) ----
+struct VankaAssembleParams {
+  const double *Kc, *Mc; // cell matrices of the cell layers [zw0, zw1)
+  double *B;             // [cell of the batch][m][m]
+  int ncx, ncy, ncz, p, nb, dmask;
+  int zw0;               // first cell layer held in Kc / Mc
+  int z0, ncells_batch;  // the batch: cell layers from z0, ncells_batch cells
+  double Alpha[VK_MAX_BLOCKS * VK_MAX_BLOCKS], Beta[VK_MAX_BLOCKS * VK_MAX_BLOCKS];
+};
+
+// One workgroup per cell: the restriction of the ASSEMBLED K, M to the cell's DoFs (own cell matrix + what the neighbours add on
+// shared faces, edges and vertices: compute_block_matrix.h:50-139), zero-boundary rows / columns with the diagonal kept, valence
+// scaling of the rows, Kronecker with Alpha / Beta (stmg.h:806-829).  Same steps as vanka_create_per_cell_host.
+__global__ __launch_bounds__(256) void vanka_assemble_kernel(const VankaAssembleParams prm)
+{
+  const int n = prm.p + 1, nloc = n * n * n, m = prm.nb * nloc;
+  const int lc = blockIdx.x; // cell of the batch
+  const int cpl = prm.ncx * prm.ncy;
+  const int cz = prm.z0 + lc / cpl, cy = (lc % cpl) / prm.ncx, cx = lc % prm.ncx;
+  const int cc[3] = {cx, cy, cz}, nc[3] = {prm.ncx, prm.ncy, prm.ncz};
+  double *B = prm.B + (size_t)lc * m * m;
+  for (int e = threadIdx.x; e < nloc * nloc; e += blockDim.x) {
+    const int a = e / nloc, b = e % nloc;
+    const int ia[3] = {a % n, (a / n) % n, a / (n * n)}, ib[3] = {b % n, (b / n) % n, b / (n * n)};
+    double val = 1.0;
+    bool con_a = false, con_b = false;
+    int lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if ((ia[d] == 0 && cc[d] > 0) || (ia[d] == prm.p && cc[d] < nc[d] - 1)) val *= 2.0;
+      const bool lo_face = cc[d] == 0 && (prm.dmask & (1 << (2 * d))), hi_face = cc[d] == nc[d] - 1 && (prm.dmask & (2 << (2 * d)));
+      con_a = con_a || (ia[d] == 0 && lo_face) || (ia[d] == prm.p && hi_face);
+      con_b = con_b || (ib[d] == 0 && lo_face) || (ib[d] == prm.p && hi_face);
+      lo[d] = (ia[d] == 0 && ib[d] == 0 && cc[d] > 0) ? -1 : 0;
+      hi[d] = (ia[d] == prm.p && ib[d] == prm.p && cc[d] < nc[d] - 1) ? 1 : 0;
+    }
+    double ks = 0.0, ms = 0.0;
+    if (a == b || !(con_a || con_b)) {
+      for (int sz = lo[2]; sz <= hi[2]; ++sz)
+        for (int sy = lo[1]; sy <= hi[1]; ++sy)
+          for (int sx = lo[0]; sx <= hi[0]; ++sx) {
+            const int sh[3] = {sx, sy, sz};
+            int a2 = 0, b2 = 0, mul = 1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              a2 += (sh[d] == -1 ? prm.p : (sh[d] == 1 ? 0 : ia[d])) * mul;
+              b2 += (sh[d] == -1 ? prm.p : (sh[d] == 1 ? 0 : ib[d])) * mul;
+              mul *= n;
+            }
+            const size_t c2 = (size_t)(cx + sx) + (size_t)prm.ncx * ((cy + sy) + (size_t)prm.ncy * (cz + sz - prm.zw0));
+            ks += prm.Kc[(c2 * nloc + a2) * nloc + b2];
+            ms += prm.Mc[(c2 * nloc + a2) * nloc + b2];
+          }
+    }
+    for (int i = 0; i < prm.nb; ++i)
+      for (int j = 0; j < prm.nb; ++j)
+        B[(size_t)(i * nloc + a) * m + j * nloc + b] = val * (prm.Beta[i * prm.nb + j] * ms + prm.Alpha[i * prm.nb + j] * ks);
+  }
+}
+
+// In-place Gauss-Jordan inverse with partial pivoting (FullMatrix::gauss_jordan, stmg.h:828; the steps of invert() above), one
+// workgroup per m x m matrix in global memory, then the block in the apply's layout: out[k][r] = T(inverse(r, k)), row stride mpad.
+template <typename T>
+__global__ __launch_bounds__(256) void vanka_invert_kernel(double *__restrict__ Ball, T *__restrict__ out_all, int m, int mpad, int kpad,
+                                                            long long cell0, int *__restrict__ singular)
+{
+  __shared__ double rowc[VK_MAX_ROWS];
+  __shared__ int piv[VK_MAX_ROWS];
+  __shared__ double rbest[256];
+  __shared__ int rarg[256];
+  double *A = Ball + (size_t)blockIdx.x * m * m;
+  const int t = threadIdx.x;
+  for (int c = 0; c < m; ++c) {
+    double best = -1.0;
+    int arg = c;
+    for (int r = c + t; r < m; r += 256) {
+      const double v = fabs(A[(size_t)r * m + c]);
+      if (v > best) { best = v; arg = r; }
+    }
+    rbest[t] = best;
+    rarg[t] = arg;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) {
+        // the first (lowest) row among equal magnitudes, as the sequential search picks it
+        if (rbest[t + s] > rbest[t] || (rbest[t + s] == rbest[t] && rarg[t + s] < rarg[t])) { rbest[t] = rbest[t + s]; rarg[t] = rarg[t + s]; }
+      }
+      __syncthreads();
+    }
+    const int p = rarg[0];
+    const double pv = rbest[0];
+    if (pv <= 0.0) {
+      if (t == 0) *singular = 1;
+      return;
+    }
+    if (t == 0) piv[c] = p;
+    // swap rows c and p, scale the pivot row, keep it in LDS
+    const double inv = 1.0 / A[(size_t)p * m + c];
+    __syncthreads(); // (every thread has read the pivot before the row is rewritten)
+    for (int k = t; k < m; k += 256) {
+      const double up = A[(size_t)p * m + k], uc = A[(size_t)c * m + k];
+      if (p != c) A[(size_t)p * m + k] = uc;
+      const double v = (k == c ? 1.0 : up) * inv;
+      A[(size_t)c * m + k] = v;
+      rowc[k] = v;
+    }
+    __syncthreads();
+    // eliminate column c from every other row: a wave takes a row at a time, lanes along the row
+    const int wave = t >> 6, lane = t & 63;
+    for (int r = wave; r < m; r += 4) {
+      if (r == c) continue;
+      const double f = A[(size_t)r * m + c];
+      if (f == 0.0) continue;
+      for (int k = lane; k < m; k += 64) {
+        const double v = (k == c ? 0.0 : A[(size_t)r * m + k]) - f * rowc[k];
+        A[(size_t)r * m + k] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // undo the row exchanges on the columns, last first
+  for (int c = m - 1; c >= 0; --c) {
+    const int p = piv[c];
+    if (p != c) {
+      for (int r = t; r < m; r += 256) {
+        const double a = A[(size_t)r * m + c];
+        A[(size_t)r * m + c] = A[(size_t)r * m + p];
+        A[(size_t)r * m + p] = a;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  T *out = out_all + (size_t)(cell0 + blockIdx.x) * kpad * mpad;
+  for (int e = t; e < kpad * mpad; e += 256) {
+    const int k = e / mpad, r = e % mpad;
+    out[e] = (k < m && r < m) ? T(A[(size_t)r * m + k]) : T(0);
+  }
+}
+
 // in-place Gauss-Jordan inverse with partial pivoting (FullMatrix::gauss_jordan, stmg.h:828)
 bool invert(int n, std::vector<double> &A)
 {
@@ -407,12 +549,40 @@ static void vanka_plan(stfem_vanka *v, int tiles)
   }
 }
 
+// DoF offsets of a cell and the cells of every colour (per-cell variant)
+static int vanka_per_cell_tables(stfem_vanka *v)
+{
+  stfem_ctx *c = v->ctx;
+  const int n = c->p + 1, nloc = v->nloc;
+  const int ncx = c->nc[0], ncy = c->nc[1], ncz = c->nc[2];
+  // ---- DoF offsets and the cells of every colour
+  std::vector<int> off(nloc);
+  for (int kz = 0; kz < n; ++kz)
+    for (int jy = 0; jy < n; ++jy)
+      for (int ix = 0; ix < n; ++ix) off[ix + n * (jy + n * kz)] = ix + c->nd[0] * (jy + c->nd[1] * kz);
+  if (hipMalloc(&v->d_off, nloc * sizeof(int)) != hipSuccess ||
+      hipMemcpy(v->d_off, off.data(), nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    return STFEM_ERR_HIP;
+  for (int colour = 0; colour < 8; ++colour) {
+    std::vector<int> cells;
+    for (int cz = colour >> 2; cz < ncz; cz += 2)
+      for (int cy = (colour >> 1) & 1; cy < ncy; cy += 2)
+        for (int cx = colour & 1; cx < ncx; cx += 2) cells.push_back(cx + ncx * (cy + ncy * cz));
+    v->ncol[colour] = int(cells.size());
+    if (cells.empty()) continue;
+    if (hipMalloc(&v->d_cell[colour], cells.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(v->d_cell[colour], cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+      return STFEM_ERR_HIP;
+  }
+  return STFEM_OK;
+}
+
 // Set-up of the per-cell blocks (general meshes, coefficient tables): cell matrices on the device from the stored
 // metric, then on the host the reference's steps one by one (stmg.h:786-829, compute_block_matrix.h:50-139):
 // restriction of the assembled matrices to the cell's DoFs (= the cell's own matrix + what the neighbours add on
 // shared faces, edges and vertices), zero-boundary rows / columns, valence scaling, Kronecker with Alpha / Beta,
 // Gauss-Jordan.  Meant for the mesh sizes the reference can hold too (one (n_blocks nloc)^2 block per cell).
-static int vanka_create_per_cell(stfem_vanka *v, const double *Alpha, const double *Beta)
+static int vanka_create_per_cell_host(stfem_vanka *v, const double *Alpha, const double *Beta)
 {
   stfem_ctx *c = v->ctx;
   const int p = c->p, n = p + 1, nloc = v->nloc, m = v->m, nb = v->nb;
@@ -544,26 +714,103 @@ static int vanka_create_per_cell(stfem_vanka *v, const double *Alpha, const doub
   if (hipMalloc(&v->d_blocks, size_t(c->ncells) * bsz * c->es) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
   if (hipMemcpy(v->d_blocks, hostp, size_t(c->ncells) * bsz * c->es, hipMemcpyHostToDevice) != hipSuccess) return STFEM_ERR_HIP;
   v->nclasses = int(c->ncells);
-  // ---- DoF offsets and the cells of every colour
-  std::vector<int> off(nloc);
-  for (int kz = 0; kz < n; ++kz)
-    for (int jy = 0; jy < n; ++jy)
-      for (int ix = 0; ix < n; ++ix) off[ix + n * (jy + n * kz)] = ix + c->nd[0] * (jy + c->nd[1] * kz);
-  if (hipMalloc(&v->d_off, nloc * sizeof(int)) != hipSuccess ||
-      hipMemcpy(v->d_off, off.data(), nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-    return STFEM_ERR_HIP;
-  for (int colour = 0; colour < 8; ++colour) {
-    std::vector<int> cells;
-    for (int cz = colour >> 2; cz < ncz; cz += 2)
-      for (int cy = (colour >> 1) & 1; cy < ncy; cy += 2)
-        for (int cx = colour & 1; cx < ncx; cx += 2) cells.push_back(cx + ncx * (cy + ncy * cz));
-    v->ncol[colour] = int(cells.size());
-    if (cells.empty()) continue;
-    if (hipMalloc(&v->d_cell[colour], cells.size() * sizeof(int)) != hipSuccess ||
-        hipMemcpy(v->d_cell[colour], cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-      return STFEM_ERR_HIP;
+  return vanka_per_cell_tables(v);
+}
+
+// The per-cell blocks built on the device, a few cell layers at a time: cell matrices of the layers and their neighbours
+// (vanka_cell_matrices_kernel), assembly of the restricted, weighted, Kronecker-combined block (vanka_assemble_kernel), batched
+// Gauss-Jordan (vanka_invert_kernel) straight into the apply's layout.  Nothing but Alpha / Beta crosses the host.
+static int vanka_create_per_cell_device(stfem_vanka *v, const double *Alpha, const double *Beta)
+{
+  stfem_ctx *c = v->ctx;
+  const int p = c->p, n = p + 1, nloc = v->nloc, m = v->m, nb = v->nb;
+  v->per_cell = true;
+  v->mt = (m + 15) / 16;
+  v->mpad = 16 * v->mt;
+  v->kpad = ((m + 3) / 4) * 4;
+  const size_t bsz = size_t(v->kpad) * v->mpad;
+  const int ncx = c->nc[0], ncy = c->nc[1], ncz = c->nc[2];
+  const size_t cpl = size_t(ncx) * ncy;
+  const size_t km_layer = 2 * cpl * nloc * nloc * sizeof(double), b_layer = cpl * size_t(m) * m * sizeof(double);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  const double need = double(c->ncells) * double(bsz) * double(c->es);
+  const double budget = 6e9; // scratch of one batch
+  if (need + 3.0 * double(km_layer) + double(b_layer) > 0.9 * double(free_b)) {
+    snprintf(g_vanka_err, sizeof(g_vanka_err), "per-cell blocks of %lld cells need %.1f GB (%.1f GB free)", (long long)c->ncells, need * 1e-9, double(free_b) * 1e-9);
+    return STFEM_ERR_OUT_OF_MEMORY;
   }
-  return STFEM_OK;
+  int L = int((budget - 2.0 * double(km_layer)) / double(km_layer + b_layer));
+  L = std::max(1, std::min(L, ncz));
+  const void *metric = nullptr;
+  int rc = stfem_internal_metric(c, &metric, nullptr);
+  if (rc != STFEM_OK) return rc;
+  double *d_tab = nullptr, *d_K = nullptr, *d_M = nullptr, *d_B = nullptr;
+  int *d_flag = nullptr;
+  auto cleanup = [&]() {
+    (void)hipFree(d_tab);
+    (void)hipFree(d_K);
+    (void)hipFree(d_M);
+    (void)hipFree(d_B);
+    (void)hipFree(d_flag);
+  };
+  std::vector<double> tabs(2 * n * n);
+  for (int i = 0; i < n * n; ++i) { tabs[i] = c->tab.S[i]; tabs[n * n + i] = c->tab.D[i]; }
+  const size_t win_cells = cpl * size_t(std::min(ncz, L + 2));
+  if (hipMalloc(&v->d_blocks, size_t(c->ncells) * bsz * c->es) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+  if (hipMalloc(&d_tab, tabs.size() * sizeof(double)) != hipSuccess || hipMalloc(&d_K, win_cells * nloc * nloc * sizeof(double)) != hipSuccess ||
+      hipMalloc(&d_M, win_cells * nloc * nloc * sizeof(double)) != hipSuccess || hipMalloc(&d_B, cpl * L * size_t(m) * m * sizeof(double)) != hipSuccess ||
+      hipMalloc(&d_flag, sizeof(int)) != hipSuccess) {
+    cleanup();
+    return STFEM_ERR_OUT_OF_MEMORY;
+  }
+  hipError_t e = hipMemcpy(d_tab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d_flag, 0, sizeof(int));
+  VankaAssembleParams ap;
+  ap.Kc = d_K; ap.Mc = d_M; ap.B = d_B;
+  ap.ncx = ncx; ap.ncy = ncy; ap.ncz = ncz; ap.p = p; ap.nb = nb; ap.dmask = c->dmask;
+  for (int i = 0; i < nb * nb; ++i) { ap.Alpha[i] = Alpha[i]; ap.Beta[i] = Beta[i]; }
+  const size_t lds = (size_t(nloc) * 7 + 2 * n * n) * sizeof(double);
+  for (int z0 = 0; z0 < ncz && e == hipSuccess; z0 += L) {
+    const int z1 = std::min(ncz, z0 + L), zw0 = std::max(0, z0 - 1), zw1 = std::min(ncz, z1 + 1);
+    const size_t wcells = cpl * size_t(zw1 - zw0), bcells = cpl * size_t(z1 - z0);
+    const size_t moff = cpl * size_t(zw0) * nloc * 8; // metric records [cell][q][8]
+    if (c->prec)
+      hipLaunchKernelGGL(vanka_cell_matrices_kernel<float>, dim3((unsigned)wcells), dim3(256), lds, 0, n, static_cast<const float *>(metric) + moff, d_tab,
+                         d_tab + n * n, d_K, d_M);
+    else
+      hipLaunchKernelGGL(vanka_cell_matrices_kernel<double>, dim3((unsigned)wcells), dim3(256), lds, 0, n, static_cast<const double *>(metric) + moff, d_tab,
+                         d_tab + n * n, d_K, d_M);
+    ap.zw0 = zw0; ap.z0 = z0; ap.ncells_batch = int(bcells);
+    hipLaunchKernelGGL(vanka_assemble_kernel, dim3((unsigned)bcells), dim3(256), 0, 0, ap);
+    const long long cell0 = (long long)cpl * z0;
+    if (c->prec)
+      hipLaunchKernelGGL(vanka_invert_kernel<float>, dim3((unsigned)bcells), dim3(256), 0, 0, d_B, static_cast<float *>(v->d_blocks), m, v->mpad, v->kpad, cell0, d_flag);
+    else
+      hipLaunchKernelGGL(vanka_invert_kernel<double>, dim3((unsigned)bcells), dim3(256), 0, 0, d_B, static_cast<double *>(v->d_blocks), m, v->mpad, v->kpad, cell0,
+                         d_flag);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize(); // (the next batch reuses the scratch)
+  }
+  int flag = 0;
+  if (e == hipSuccess) e = hipMemcpy(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) {
+    snprintf(g_vanka_err, sizeof(g_vanka_err), "per-cell block set-up: %s", hipGetErrorString(e));
+    return STFEM_ERR_HIP;
+  }
+  if (flag) {
+    snprintf(g_vanka_err, sizeof(g_vanka_err), "singular cell block");
+    return STFEM_ERR_INVALID_ARGUMENT;
+  }
+  v->nclasses = int(c->ncells);
+  return vanka_per_cell_tables(v);
+}
+
+static int vanka_create_per_cell(stfem_vanka *v, const double *Alpha, const double *Beta)
+{
+  const char *e = getenv("STFEM_VANKA_HOST_SETUP"); // the same steps on the host, block by block (for comparison; small meshes only)
+  return (e && atoi(e) != 0) ? vanka_create_per_cell_host(v, Alpha, Beta) : vanka_create_per_cell_device(v, Alpha, Beta);
 }
 
 extern "C" {

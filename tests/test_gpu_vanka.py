@@ -117,3 +117,23 @@ def test_vanka_blocks_at_descending_addresses():
         dst.upload(np.full((nb, ctx.n_dofs), 1e30))  # every entry must be overwritten
         V.vmult(dst, src)
         assert rel(dst.download(), ref.vmult(X)) < 1e-10, order
+
+
+@pytest.mark.parametrize("number", ["double", "float"])
+def test_vanka_device_setup_equals_host_setup(number, monkeypatch):
+    """the per-cell blocks assembled and inverted on the device (batched Gauss-Jordan) against the same steps on the host"""
+    stfem = importlib.import_module("dealii-stfem_amd")
+    p, nc = 3, (3, 2, 4)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(0, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=stfem.mesh_vertices(nc, distort=0.12, seed=4), number=number, dirichlet_mask=63 & ~16)
+    X = np.random.default_rng(2).uniform(-1, 1, (nb, ctx.n_dofs))
+    out = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("STFEM_VANKA_HOST_SETUP", host)
+        V = stfem.PreconditionVanka(ctx, Alpha, Beta)
+        assert V.n_classes == nc[0] * nc[1] * nc[2]
+        src, dst = stfem.BlockVector(ctx, nb).upload(X), stfem.BlockVector(ctx, nb)
+        V.vmult(dst, src)
+        out.append(dst.download())
+    assert rel(out[0], out[1]) < (1e-11 if number == "double" else 1e-5)
