@@ -6,7 +6,7 @@
 // on the preconditioner, the iteration counts do).
 // With mg=1 the preconditioner is the reference's own: one V-cycle of the space-time multigrid (host/stfem/stmg.h), levels as
 // tests/tp_01.cc:170-200 derives them.  Options (key=value, anywhere): mg=0|1, mg_float=0|1 (multigrid in fp32, stmg.h:1330-1343),
-// coarsening=space_or_time|space_and_time, pmg=0|1, kmin=<lowest temporal degree>, relaxation=<omega, 0 = estimated>, variable=0|1, steps=<n>
+// distort=<vertex jitter in h>, coarsening=space_or_time|space_and_time, pmg=0|1, kmin=<lowest temporal degree>, relaxation=<omega, 0 = estimated>, variable=0|1, steps=<n>
 // Usage: heat_convergence <type 0 = cG | 1 = dG> <k> <refinement> <n_timesteps_at_once> [vanka sweeps = 2, 0 = none] [omega = 0.5]
 //                         [fe_degree = k + 1] [cells per direction = 2^refinement] [end_time = 1] [FGMRES steps = 200]
 // Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
@@ -49,6 +49,8 @@ int main(int argc_all, char **argv_all)
   try {
     Mesh mesh;
     mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = n;
+    const double distort = std::atof(option("distort", "0").c_str()); // GridTools::distort_random (tests/tp_01.cc:89-90): general-geometry path, per-cell Vanka blocks
+    if (distort > 0) mesh.distort_random(distort);
     MatrixFreeOperatorScalar<3, Number> K_mf(mesh, fe_degree, 0.0, 1.0), M_mf(K_mf, 1.0, 0.0);
     auto [Alpha, Beta, Gamma, Zeta] = get_fe_time_weights<Number>(type, k, tau, nsteps);
     auto [Alpha_1, Beta_1, Gamma_1, Zeta_1] = get_fe_time_weights<Number>(type, k, tau, 1);
