@@ -126,3 +126,44 @@ def test_stokes_vmult_slice_add(stfem):
             ju, jp = stfem.stokes_block_index(nt, it, 0, d), stfem.stokes_block_index(nt, it, 1, d)
             assert rel(dst[ju].download(), init[ju] + Gamma[ju] * ku.reshape(-1) + Zeta[ju] * mu.reshape(-1)) < TOL
             assert rel(dst[jp].download(), init[jp] + Gamma[jp] * kp) < TOL
+
+
+@pytest.mark.parametrize("nc,upper,mask", [((5, 4, 6), (1.0, 1.0, 1.0), 0b111011), ((3, 7, 2), (2.0, 0.5, 1.5), 63), ((21, 3, 3), (1.0, 1.0, 1.0), 0),
+                                           ((1, 1, 1), (1.0, 2.0, 3.0), 63)])
+def test_stokes_axis_aligned_mesh_vs_oracle(nc, upper, mask, stfem):
+    """axis-aligned meshes (no vertex array: constant diagonal Jacobian path of the kernel) against the oracle: operator, vector mass and
+    the space-time scatter"""
+    from oracle import oracle
+    nu = 0.7
+    verts = stfem.mesh_vertices(nc, (0, 0, 0), upper)
+    orc = oracle.StokesOracle(nc, verts, mask, nu)
+    rng = np.random.default_rng(21)
+    U, Pp = rng.uniform(-1, 1, 3 * orc.n_u), rng.uniform(-1, 1, orc.n_p)
+    ku, kp = orc.apply(U, Pp)
+    mu, _ = orc.apply(U, Pp, 0.0, 1.0)
+    results = []
+    for plane in ("-",):
+        op = stfem.StokesMatrixFreeOperator(nc, upper=upper, dirichlet_mask=mask, viscosity=nu)
+        u, p = op.initialize_dof_vector(0, U), op.initialize_dof_vector(1, Pp)
+        ou, opr = op.initialize_dof_vector(0, np.full(3 * op.n_velocity, 7.0)), op.initialize_dof_vector(1, np.full(op.n_pressure, -3.0))
+        op.vmult(ou, opr, u, p)
+        m = op.initialize_dof_vector(0, np.full(3 * op.n_velocity, 5.0))
+        op.mass_vmult(m, u)
+        results.append((ou.download(), opr.download(), m.download()))
+        assert rel(results[-1][0], ku.reshape(-1)) < TOL and rel(results[-1][2], mu.reshape(-1)) < TOL
+        assert np.linalg.norm(results[-1][1] - kp) <= TOL * max(np.linalg.norm(kp), 1e-300) + 1e-14
+        # space-time: cG(2), one step
+        nt = 2
+        Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, 2, 1.0 / 16, 1)
+        blocks = [None] * (2 * nt)
+        r2 = np.random.default_rng(8)
+        for d in range(nt):
+            blocks[stfem.stokes_block_index(nt, 0, 0, d)] = r2.uniform(-1, 1, 3 * orc.n_u)
+            blocks[stfem.stokes_block_index(nt, 0, 1, d)] = r2.uniform(-1, 1, orc.n_p)
+        ref = orc.st_vmult(Alpha, Beta, 1, nt, blocks, True)
+        var = [0 if b.size == 3 * orc.n_u else 1 for b in blocks]
+        src = [op.initialize_dof_vector(v, b) for v, b in zip(var, blocks)]
+        dst = [op.initialize_dof_vector(v, np.full(b.size, 11.0)) for v, b in zip(var, blocks)]
+        op.st_vmult(Alpha, Beta, 1, nt, dst, src, True)
+        for j in range(2 * nt):
+            assert np.linalg.norm(dst[j].download() - ref[j]) <= TOL * np.linalg.norm(ref[j]) + 1e-14, (plane, j)
