@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <new>
 #include <vector>
 
@@ -819,7 +820,13 @@ const char *stfem_vanka_last_error(void) { return g_vanka_err; }
 
 int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *Beta, stfem_vanka **out)
 {
-  if (!c || !Alpha || !Beta || !out || nb < 1 || nb > VK_MAX_BLOCKS) return STFEM_ERR_INVALID_ARGUMENT;
+  return stfem_vanka_create_partitioned(c, nb, Alpha, Beta, 0, out);
+}
+
+int stfem_vanka_create_partitioned(stfem_ctx *c, int nb, const double *Alpha, const double *Beta, int neighbour_mask, stfem_vanka **out)
+{
+  if (!c || !Alpha || !Beta || !out || nb < 1 || nb > VK_MAX_BLOCKS || (neighbour_mask & ~63) || (neighbour_mask & c->dmask))
+    return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
   if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 4 temporal blocks
@@ -830,6 +837,10 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
   // one block per neighbour pattern needs identical cells: axis-aligned uniform mesh, no coefficient tables;
   // everything else gets one block per cell
   if (!c->cartesian || c->coef_layout[0] != 0 || c->coef_layout[1] != 0) {
+    if (neighbour_mask) { // (the blocks of the interface cells need the cell matrices of the neighbour rank's cells)
+      delete v;
+      return STFEM_ERR_UNSUPPORTED;
+    }
     const int rc = vanka_create_per_cell(v, Alpha, Beta);
     if (rc != STFEM_OK) {
       stfem_vanka_destroy(v);
@@ -848,8 +859,14 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
         Mh[a * n + b] += tab.wq[q] * tab.S[q * n + a] * tab.S[q * n + b];
         Kh[a * n + b] += tab.wq[q] * tab.D[q * n + a] * tab.D[q * n + b];
       }
-  // classes: per direction bit 0 = has a lower neighbour, bit 1 = has an upper neighbour
-  auto dir_class = [&](int d, int cd) { return (cd > 0 ? 1 : 0) | (cd < c->nc[d] - 1 ? 2 : 0); };
+  // classes: per direction bit 0 = has a lower neighbour, bit 1 = has an upper neighbour - on this rank or, across a face of
+  // neighbour_mask, on the rank next to it (valence and assembled entries count those cells too; what they add to the shared
+  // DoFs arrives with the caller's add-exchange of the interface planes).  local_class: neighbours on this rank only - the
+  // first-touch rule of the scatter.
+  auto local_class = [&](int d, int cd) { return (cd > 0 ? 1 : 0) | (cd < c->nc[d] - 1 ? 2 : 0); };
+  auto dir_class = [&](int d, int cd) {
+    return local_class(d, cd) | ((cd == 0 && (neighbour_mask & (1 << (2 * d)))) ? 1 : 0) | ((cd == c->nc[d] - 1 && (neighbour_mask & (2 << (2 * d)))) ? 2 : 0);
+  };
   std::map<int, int> class_id;
   std::vector<int> class_key;
   for (int cz = 0; cz < c->nc[2]; ++cz)
@@ -957,19 +974,19 @@ int stfem_vanka_create(stfem_ctx *c, int nb, const double *Alpha, const double *
   }
   // cell lists: per colour, grouped by class into batches of 16 cells, four batches of one class per workgroup
   for (int colour = 0; colour < 8; ++colour) {
-    std::vector<std::vector<int>> by_class(v->nclasses);
+    std::map<std::pair<int, int>, std::vector<int>> by_class; // (block class, local neighbour pattern) -> cells
     for (int cz = colour >> 2; cz < c->nc[2]; cz += 2)
       for (int cy = (colour >> 1) & 1; cy < c->nc[1]; cy += 2)
         for (int cx = colour & 1; cx < c->nc[0]; cx += 2) {
           const int key = dir_class(0, cx) | (dir_class(1, cy) << 2) | (dir_class(2, cz) << 4);
-          by_class[class_id[key]].push_back(p * cx + c->nd[0] * (p * cy + c->nd[1] * p * cz));
+          const int local = local_class(0, cx) | (local_class(1, cy) << 2) | (local_class(2, cz) << 4);
+          by_class[{class_id[key], local}].push_back(p * cx + c->nd[0] * (p * cy + c->nd[1] * p * cz));
         }
     std::vector<int> cells, cls;
-    for (int ci = 0; ci < v->nclasses; ++ci) {
-      std::vector<int> &l = by_class[ci];
-      if (l.empty()) continue;
+    for (auto &kv : by_class) {
+      std::vector<int> &l = kv.second;
       l.resize(((l.size() + 63) / 64) * 64, -1);
-      for (size_t q = 0; q < l.size() / 64; ++q) cls.push_back(ci | (class_key[ci] << 8));
+      for (size_t q = 0; q < l.size() / 64; ++q) cls.push_back(kv.first.first | (kv.first.second << 8));
       cells.insert(cells.end(), l.begin(), l.end());
     }
     v->nquad[colour] = int(cls.size());

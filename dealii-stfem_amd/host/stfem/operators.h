@@ -285,7 +285,9 @@ public:
       b[i] = double(Beta.data()[i]);
     }
     stfem_vanka *v = nullptr;
-    const int rc = stfem_vanka_create(ctx_->h, int(Alpha.m()), a.data(), b.data(), &v);
+    // on a slab of a partitioned mesh (MatrixFreeOperator::set_partition BEFORE this constructor) the cells behind the interface faces count
+    const int neighbours = (ctx_->lower_rank >= 0 ? 16 : 0) | (ctx_->upper_rank >= 0 ? 32 : 0);
+    const int rc = stfem_vanka_create_partitioned(ctx_->h, int(Alpha.m()), a.data(), b.data(), neighbours, &v);
     if (rc != STFEM_OK) throw Error(rc, std::string("stfem_vanka_create: ") + stfem_vanka_last_error());
     v_.reset(v, stfem_vanka_destroy);
   }
@@ -293,6 +295,7 @@ public:
   {
     const int rc = stfem_vanka_vmult(v_.get(), dst.handle(), src.handle(), stream);
     if (rc != STFEM_OK) throw Error(rc, std::string("PreconditionVanka::vmult: ") + stfem_vanka_last_error());
+    compress_add(*ctx_, dst.handle(), stream); // partitioned: the interface planes hold partial sums (dst.compress(add) in the reference)
   }
   void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
   void clear() { v_.reset(); }

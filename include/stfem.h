@@ -261,6 +261,12 @@ void stfem_graph_destroy(stfem_graph *g);
  * dst is overwritten, dst must not alias src (as in the reference). */
 typedef struct stfem_vanka stfem_vanka;
 int stfem_vanka_create(stfem_ctx *ctx, int n, const double *alpha, const double *beta, stfem_vanka **out);
+/* the same on one slab of a partitioned mesh: neighbour_mask (bits as dirichlet_mask) names the faces behind which another rank
+ * holds the next cells.  The blocks and valences of the cells at such a face count the cells beyond it, as the reference's do on
+ * a parallel::distributed::Triangulation (ghost cells); stfem_vanka_vmult then leaves PARTIAL sums in the interface planes of
+ * dst, to be completed by the add-exchange of the operator (stfem_halo_begin / end).  Axis-aligned uniform meshes only
+ * (STFEM_ERR_UNSUPPORTED for one-block-per-cell contexts). */
+int stfem_vanka_create_partitioned(stfem_ctx *ctx, int n, const double *alpha, const double *beta, int neighbour_mask, stfem_vanka **out);
 void stfem_vanka_destroy(stfem_vanka *v);
 int stfem_vanka_n_classes(const stfem_vanka *v); /* distinct cell blocks held */
 /* diagnostics: {row tiles (16 rows) per workgroup, parts per cell block} */

@@ -108,3 +108,69 @@ def test_slab_exchange_on_one_gpu(stfem, oracle_mod, p, gnc, world, distort, num
     assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"], R["bufs"]["ts"], None) != 0
     assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, -1, R["bufs"]["ts"], 1, None) != 0
     assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, None, None) != 0
+
+
+@pytest.mark.parametrize("p,gnc,world,number", [(2, (4, 3, 6), 2, "double"), (4, (3, 2, 6), 3, "double"), (3, (2, 3, 4), 2, "float")])
+def test_partitioned_vanka_on_one_gpu(stfem, p, gnc, world, number):
+    """The cell-patch Vanka smoother on z-slabs (stfem_vanka_create_partitioned: the cells behind an interface face count in blocks and
+    valences, the apply leaves partial sums in the interface planes) + the add-exchange of the planes == the smoother of the whole mesh."""
+    import ctypes
+    dmod = importlib.import_module("dealii-stfem_amd.distributed")
+    L = stfem.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    esz = 8 if number == "double" else 4
+    tol = 1e-12 if number == "double" else 2e-5
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    plane = (p * gnc[0] + 1) * (p * gnc[1] + 1)
+    upper = (1.0, 1.0, 1.5)
+    ndofs = plane * (p * gnc[2] + 1)
+    X = np.random.default_rng(3).uniform(-1, 1, (nb, ndofs))
+    if number == "float":
+        X = X.astype(np.float32).astype(float)
+    gctx = stfem.MatrixFreeOperator(p, gnc, upper=upper, number=number)
+    gV = stfem.PreconditionVanka(gctx, Alpha, Beta)
+    gdst = stfem.BlockVector(gctx, nb)
+    gV.vmult(gdst, stfem.BlockVector(gctx, nb).upload(X))
+    Y = gdst.download()
+    ranks = []
+    for r in range(world):
+        slab = dmod.make_slab(gnc, r, world)
+        lo_z, hi_z = upper[2] * slab.z0 / gnc[2], upper[2] * slab.z1 / gnc[2]
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, lower=(0, 0, lo_z), upper=(upper[0], upper[1], hi_z), number=number,
+                                       dirichlet_mask=slab.dirichlet_mask(63))
+        nmask = (16 if slab.has_lower else 0) | (32 if slab.has_upper else 0)
+        V = stfem.PreconditionVanka(ctx, Alpha, Beta, neighbour_mask=nmask)
+        lo, hi = p * slab.z0 * plane, (p * slab.z1 + 1) * plane
+        dst = stfem.BlockVector(ctx, nb)
+        V.vmult(dst, stfem.BlockVector(ctx, nb).upload(X[:, lo:hi]))
+        hold = stfem.BlockVector(ctx, 4)
+        nzl = p * (slab.z1 - slab.z0) + 1
+        ranks.append(dict(slab=slab, ctx=ctx, V=V, dst=dst, hold=hold, nzl=nzl, lo=lo, hi=hi,
+                          bufs={k: hold.block_ptr(q) for q, k in enumerate(("ts", "bs", "tr", "br"))}))
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["ts"], None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["bs"], None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for r, R in enumerate(ranks):
+        if R["slab"].has_upper:
+            assert hip.hipMemcpy(ranks[r + 1]["bufs"]["br"], R["bufs"]["ts"], nb * plane * esz, 3) == 0
+        if R["slab"].has_lower:
+            assert hip.hipMemcpy(ranks[r - 1]["bufs"]["tr"], R["bufs"]["bs"], nb * plane * esz, 3) == 0
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["tr"], 1, None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["br"], 1, None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for R in ranks:
+        assert rel(R["dst"].download(), Y[:, R["lo"]:R["hi"]]) < tol
+    # a mask naming a Dirichlet face, and per-cell contexts, are refused
+    with pytest.raises(stfem.StfemError):
+        stfem.PreconditionVanka(gctx, Alpha, Beta, neighbour_mask=16)
+    pert = stfem.MatrixFreeOperator(p, (2, 2, 2), vertices=stfem.mesh_vertices((2, 2, 2), distort=0.1), dirichlet_mask=63 & ~32, number=number)
+    with pytest.raises(stfem.StfemError):
+        stfem.PreconditionVanka(pert, Alpha, Beta, neighbour_mask=32)
