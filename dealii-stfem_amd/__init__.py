@@ -106,6 +106,7 @@ SIGNATURES = {
     "stfem_mg_sequence": (C.c_int, [C.c_int] * 5 + [C.c_char] + [C.c_int] * 4 + [C.c_char_p, C.POINTER(C.c_int32)]),
     "stfem_precondition_stmg_types": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "stfem_transfer_create": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    "stfem_transfer_create_partitioned": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp)]),
     "stfem_transfer_destroy": (None, [_vp]),
     "stfem_transfer_prolongate": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "stfem_transfer_restrict": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
@@ -524,10 +525,11 @@ def get_precondition_stmg_types(mg_type_level, coarsening_type="space_and_time",
 class MGTwoLevelTransfer:
     """deal.II MGTwoLevelTransfer between two contexts as MGTwoLevelBlockTransfer uses it (stmg.h:38-110)."""
 
-    def __init__(self, fine, coarse):
+    def __init__(self, fine, coarse, neighbour_mask=0):
+        """neighbour_mask: 16 = a slab below, 32 = a slab above (z-slab partition)"""
         self.fine, self.coarse = fine, coarse
         h = _vp()
-        _check(lib().stfem_transfer_create(fine._h, coarse._h, C.byref(h)), "stfem_transfer_create")
+        _check(lib().stfem_transfer_create_partitioned(fine._h, coarse._h, neighbour_mask, C.byref(h)), "stfem_transfer_create")
         self._h = h
 
     def __del__(self):

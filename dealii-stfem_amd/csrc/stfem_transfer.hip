@@ -223,6 +223,7 @@ struct stfem_transfer {
   Band P[3], R[3], I[3]; // per direction: prolongation rows, its transpose, nodal interpolation (all with the constraints)
   // cell form of P / R along y and z: local embedding matrix, coarse degree, fine nodes per coarse cell, coarse cells, constrained ends
   double L[3][9 * 5];
+  bool cell_restrict_z = true;
   bool cell_form = true; // STFEM_TRANSFER_TABLES=1: table-driven passes along every axis (for comparison)
   int pc[3] = {0, 0, 0}, Rn[3] = {0, 0, 0}, ncc[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
   void *d_tmp[2] = {nullptr, nullptr};
@@ -298,7 +299,7 @@ int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const 
     dims[ax] = B[ax].n_out;
     T *dst = step == 2 ? static_cast<T *>(out) : static_cast<T *>(t->d_tmp[step]);
     int st = 1;
-    if (cell && ax > 0 && t->Rn[ax] > t->pc[ax]) { // (an axis with the same cells and degree on both levels is a copy: table-driven)
+    if (cell && ax > 0 && t->Rn[ax] > t->pc[ax] && !(cell == 2 && ax == 2 && !t->cell_restrict_z)) { // (an axis with the same cells and degree on both levels is a copy: table-driven)
       const long long S = ax == 1 ? dims[0] : (long long)dims[0] * dims[1];
       const long long total = S * t->ncc[ax] * (ax == 1 ? dims[2] : 1);
       st = launch_cell<T>(cell == 1, t->pc[ax], t->Rn[ax], dst, cur, S, t->ncc[ax], total, t->L[ax], t->flags[ax], step == 2 ? add : 0, s);
@@ -335,7 +336,12 @@ const char *stfem_transfer_last_error(void) { return g_transfer_err; }
 
 int stfem_transfer_create(stfem_ctx *fine, stfem_ctx *coarse, stfem_transfer **out)
 {
-  if (!fine || !coarse || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  return stfem_transfer_create_partitioned(fine, coarse, 0, out);
+}
+
+int stfem_transfer_create_partitioned(stfem_ctx *fine, stfem_ctx *coarse, int neighbour_mask, stfem_transfer **out)
+{
+  if (!fine || !coarse || !out || (neighbour_mask & ~48) || (neighbour_mask & (fine->dmask | coarse->dmask))) return STFEM_ERR_INVALID_ARGUMENT;
   if (fine->prec != coarse->prec || fine->device != coarse->device) return STFEM_ERR_SHAPE_MISMATCH;
   for (int d = 0; d < 3; ++d) {
     const bool same = fine->nc[d] == coarse->nc[d], twice = fine->nc[d] == 2 * coarse->nc[d];
@@ -354,12 +360,16 @@ int stfem_transfer_create(stfem_ctx *fine, stfem_ctx *coarse, stfem_transfer **o
     const int n_f = fine->nd[d], n_c = coarse->nd[d];
     // zero-boundary constraints of both levels: constrained rows are not written, constrained columns read as 0
     auto constrained = [&](const stfem_ctx *c, int i, int n) { return (i == 0 && (c->dmask >> (2 * d) & 1)) || (i == n - 1 && (c->dmask >> (2 * d + 1) & 1)); };
+    // a slab with a neighbour above: its top fine plane is the ghost copy of the neighbour's bottom plane (stfem.h: halo support) and
+    // is restricted THERE; here it does not contribute, and the add-exchange of the coarse interface planes completes the sums
+    const bool ghost_top = d == 2 && (neighbour_mask & 32);
     std::vector<double> R(size_t(n_c) * n_f);
     for (int f = 0; f < n_f; ++f)
       for (int c = 0; c < n_c; ++c) {
         if (constrained(fine, f, n_f) || constrained(coarse, c, n_c)) P[size_t(f) * n_c + c] = 0.0, I[size_t(c) * n_f + f] = 0.0;
-        R[size_t(c) * n_f + f] = P[size_t(f) * n_c + c];
+        R[size_t(c) * n_f + f] = (ghost_top && f == n_f - 1) ? 0.0 : P[size_t(f) * n_c + c];
       }
+    if (ghost_top) t->cell_restrict_z = false; // (the cell form of the restriction has no such mask: table-driven pass along z)
     // cell form: the block of cell 0 of the unconstrained embedding (the same in every cell)
     t->pc[d] = coarse->p;
     t->Rn[d] = (fine->nc[d] / coarse->nc[d]) * fine->p;

@@ -135,7 +135,9 @@ public:
   MGTwoLevelTransfer(const std::shared_ptr<Context> &fine, const std::shared_ptr<Context> &coarse) : fine_(fine), coarse_(coarse)
   {
     stfem_transfer *t = nullptr;
-    const int rc = stfem_transfer_create(fine->h, coarse->h, &t);
+    // z-slab partition (the same ranks below / above on both levels): the restriction leaves partial sums in the coarse interface planes
+    const int neighbours = (fine->lower_rank >= 0 ? 16 : 0) | (fine->upper_rank >= 0 ? 32 : 0);
+    const int rc = stfem_transfer_create_partitioned(fine->h, coarse->h, neighbours, &t);
     if (rc != STFEM_OK) throw Error(rc, std::string("stfem_transfer_create: ") + stfem_transfer_last_error());
     t_.reset(t, stfem_transfer_destroy);
   }
@@ -161,6 +163,7 @@ public:
   void restrict_and_add(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
     check(stfem_transfer_restrict(transfer->handle(), dst.handle(), src.handle(), 1, stream), "MGTwoLevelTransferSpace::restrict_and_add");
+    compress_add(*dst.context(), dst.handle(), stream); // partitioned: dst.compress(add) of MGTwoLevelTransfer::restrict_and_add
   }
   void interpolate(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {

@@ -224,6 +224,12 @@ int stfem_precondition_stmg_types(const char *mg_type_level, int n, int coarseni
  * Asynchronous on `stream`; one transfer object serves one stream at a time (it owns the intermediates). */
 typedef struct stfem_transfer stfem_transfer;
 int stfem_transfer_create(stfem_ctx *fine, stfem_ctx *coarse, stfem_transfer **out);
+/* the same between the two levels of one z-slab of a partitioned mesh (both contexts hold the slab: the coarse one half the cell
+ * layers or the same); neighbour_mask: bit 4 = a slab below, bit 5 = a slab above.  The prolongation is local (the coarse ghost
+ * plane must be up to date: stfem_ghost_update).  The restriction leaves PARTIAL sums in the coarse interface planes, to be
+ * completed by the add-exchange (stfem_halo_begin / end on the coarse context); the fine ghost plane (top plane under a slab
+ * above) is restricted by its owner only. */
+int stfem_transfer_create_partitioned(stfem_ctx *fine, stfem_ctx *coarse, int neighbour_mask, stfem_transfer **out);
 void stfem_transfer_destroy(stfem_transfer *t);
 int stfem_transfer_prolongate(stfem_transfer *t, stfem_vec *dst_fine, const stfem_vec *src_coarse, int add, void *stream);
 int stfem_transfer_restrict(stfem_transfer *t, stfem_vec *dst_coarse, const stfem_vec *src_fine, int add, void *stream);

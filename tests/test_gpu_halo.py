@@ -174,3 +174,67 @@ def test_partitioned_vanka_on_one_gpu(stfem, p, gnc, world, number):
     pert = stfem.MatrixFreeOperator(p, (2, 2, 2), vertices=stfem.mesh_vertices((2, 2, 2), distort=0.1), dirichlet_mask=63 & ~32, number=number)
     with pytest.raises(stfem.StfemError):
         stfem.PreconditionVanka(pert, Alpha, Beta, neighbour_mask=32)
+
+
+@pytest.mark.parametrize("pf,pc,gf,gc,world,number", [(2, 2, (4, 4, 8), (2, 2, 4), 2, "double"), (4, 2, (2, 3, 6), (2, 3, 6), 3, "double"),
+                                                       (3, 3, (2, 2, 12), (1, 1, 6), 3, "float")])
+def test_partitioned_space_transfer_on_one_gpu(stfem, pf, pc, gf, gc, world, number):
+    """Multigrid space transfer between the two levels of a z-slab (stfem_transfer_create_partitioned): the prolongation is local, the
+    restriction + add-exchange of the coarse interface planes == the restriction of the whole mesh (the fine ghost plane counts once)."""
+    import ctypes
+    dmod = importlib.import_module("dealii-stfem_amd.distributed")
+    L = stfem.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    esz = 8 if number == "double" else 4
+    tol = 1e-13 if number == "double" else 2e-6
+    nb = 2
+    gfine, gcoarse = stfem.MatrixFreeOperator(pf, gf, number=number), stfem.MatrixFreeOperator(pc, gc, number=number)
+    T = stfem.MGTwoLevelTransfer(gfine, gcoarse)
+    rng = np.random.default_rng(9)
+    Xf, Xc = rng.uniform(-1, 1, (nb, gfine.n_dofs)), rng.uniform(-1, 1, (nb, gcoarse.n_dofs))
+    if number == "float":
+        Xf, Xc = Xf.astype(np.float32).astype(float), Xc.astype(np.float32).astype(float)
+    rf, pc_ = stfem.BlockVector(gcoarse, nb), stfem.BlockVector(gfine, nb)
+    T.restrict_and_add(rf, stfem.BlockVector(gfine, nb).upload(Xf))
+    T.prolongate(pc_, stfem.BlockVector(gcoarse, nb).upload(Xc))
+    RX, PX = rf.download(), pc_.download()
+    plane_f, plane_c = (pf * gf[0] + 1) * (pf * gf[1] + 1), (pc * gc[0] + 1) * (pc * gc[1] + 1)
+    ranks = []
+    for r in range(world):
+        sf, sc = dmod.make_slab(gf, r, world), dmod.make_slab(gc, r, world)
+        assert sf.z0 * gc[2] == sc.z0 * gf[2] and sf.z1 * gc[2] == sc.z1 * gf[2]
+        zf = lambda z: float(z) / gf[2]  # noqa: E731
+        fine = stfem.MatrixFreeOperator(pf, sf.ncell, lower=(0, 0, zf(sf.z0)), upper=(1, 1, zf(sf.z1)), number=number, dirichlet_mask=sf.dirichlet_mask(63))
+        coarse = stfem.MatrixFreeOperator(pc, sc.ncell, lower=(0, 0, zf(sf.z0)), upper=(1, 1, zf(sf.z1)), number=number, dirichlet_mask=sc.dirichlet_mask(63))
+        Tr = stfem.MGTwoLevelTransfer(fine, coarse, neighbour_mask=(16 if sf.has_lower else 0) | (32 if sf.has_upper else 0))
+        lof, hif = pf * sf.z0 * plane_f, (pf * sf.z1 + 1) * plane_f
+        loc, hic = pc * sc.z0 * plane_c, (pc * sc.z1 + 1) * plane_c
+        # prolongation: local
+        out_f = stfem.BlockVector(fine, nb)
+        Tr.prolongate(out_f, stfem.BlockVector(coarse, nb).upload(Xc[:, loc:hic]))
+        assert rel(out_f.download(), PX[:, lof:hif]) < tol
+        dst = stfem.BlockVector(coarse, nb)
+        Tr.restrict_and_add(dst, stfem.BlockVector(fine, nb).upload(Xf[:, lof:hif]))
+        hold = stfem.BlockVector(coarse, 4)
+        ranks.append(dict(slab=sc, ctx=coarse, fine=fine, T=Tr, dst=dst, hold=hold, nzl=pc * (sc.z1 - sc.z0) + 1, lo=loc, hi=hic,
+                          bufs={k: hold.block_ptr(q) for q, k in enumerate(("ts", "bs", "tr", "br"))}))
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["ts"], None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["bs"], None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for r, R in enumerate(ranks):
+        if R["slab"].has_upper:
+            assert hip.hipMemcpy(ranks[r + 1]["bufs"]["br"], R["bufs"]["ts"], nb * plane_c * esz, 3) == 0
+        if R["slab"].has_lower:
+            assert hip.hipMemcpy(ranks[r - 1]["bufs"]["tr"], R["bufs"]["bs"], nb * plane_c * esz, 3) == 0
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["tr"], 1, None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["br"], 1, None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for R in ranks:
+        assert rel(R["dst"].download(), RX[:, R["lo"]:R["hi"]]) < tol
