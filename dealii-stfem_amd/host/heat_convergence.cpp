@@ -1,9 +1,9 @@
 // The reference's space-time convergence test of the heat equation (tests/tp_01.cc with space_time_conv_test,
 // ProblemType::heat) in 3D on the device: u = sin(2 pi f t) prod sin(2 pi f x_d) on the unit cube, FE_Q(k + 1) in
 // space, dG(k) / cG(k) in time, tau = 2^-(refinement + 1), n_timesteps_at_once steps per solve, FGMRES
-// (200 steps, restart 100, 1e-12) preconditioned by relaxation sweeps of the cell-patch Vanka smoother
-// (the reference preconditions with its space-time multigrid, SURVEY 8 f-2, not built: the errors do not depend
-// on the preconditioner, the iteration counts do).
+// (200 steps, restart 100, 1e-12) preconditioned by relaxation sweeps of the cell-patch Vanka smoother or, with mg=1, by the
+// reference's own preconditioner, one V-cycle of the space-time multigrid (the errors do not depend on the preconditioner,
+// the iteration counts do).
 // With mg=1 the preconditioner is the reference's own: one V-cycle of the space-time multigrid (host/stfem/stmg.h), levels as
 // tests/tp_01.cc:170-200 derives them.  Options (key=value, anywhere): mg=0|1, mg_float=0|1 (multigrid in fp32, stmg.h:1330-1343),
 // distort=<vertex jitter in h>, coarsening=space_or_time|space_and_time, pmg=0|1, kmin=<lowest temporal degree>, relaxation=<omega, 0 = estimated>, variable=0|1, steps=<n>

@@ -2,9 +2,9 @@
 // ProblemType::wave: u_tt - laplace u = f, include/time_integrators.h:343-459, include/exact_solution.h:147-197)
 // in 3D on the device: u = sin(2 pi f t) prod sin(2 pi f x_d), v = u_t, on the unit cube, FE_Q(k + 1) in
 // space, dG(k) / cG(k) in time, tau = 2^-(refinement + 1), n_timesteps_at_once steps per solve, FGMRES
-// (200 steps, restart 100, 1e-12) preconditioned by relaxation sweeps of the cell-patch Vanka smoother
-// (the reference preconditions with its space-time multigrid, SURVEY 8 f-2, not built: the errors do not depend
-// on the preconditioner, the iteration counts do).
+// (200 steps, restart 100, 1e-12) preconditioned by relaxation sweeps of the cell-patch Vanka smoother or, with mg=1, by the
+// reference's own preconditioner, one V-cycle of the space-time multigrid (the errors do not depend on the preconditioner,
+// the iteration counts do).
 // Usage: wave_convergence <type 0 = cG | 1 = dG> <k> <refinement> <n_timesteps_at_once> [vanka sweeps = 2, 0 = none] [omega = 0.5]
 //                         [fe_degree = k + 1] [cells per direction = 2^refinement] [end_time = 1] [FGMRES steps = 200]
 // Prints: cells s-dofs t-dofs Linf-Linf L2-L2 L2-H1semi gmres-iterations-per-solve  (and timings on stderr)
