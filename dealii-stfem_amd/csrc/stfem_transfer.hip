@@ -211,6 +211,57 @@ cell_restrict_kernel(T *__restrict__ out, const T *__restrict__ in, long long S,
   }
 }
 
+// The same restriction as a march: a thread walks along the axis through the coarse cells [c0, c1) of its segment and keeps
+// the interior fine values of the cell before in registers, so every fine value is loaded once (cell_restrict_kernel loads the
+// previous cell's rows again: the planes of one coarse cell exceed the L2 along z, 2 x the HBM reads).
+template <typename T, int PC, int R>
+__global__ void __launch_bounds__(256)
+cell_restrict_march_kernel(T *__restrict__ out, const T *__restrict__ in, long long S, int ncell, int nseg, long long total, const CellMat<T> m, int flags,
+                           int add)
+{
+  const long long n_c = (long long)PC * ncell + 1, n_f = (long long)R * ncell + 1;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long inner = t % S, rest = t / S;
+    const int seg = int(rest % nseg);
+    const long long outer = rest / nseg;
+    const int c0 = int((long long)ncell * seg / nseg), c1 = int((long long)ncell * (seg + 1) / nseg);
+    const T *f = in + inner + S * (n_f * outer);
+    T *o = out + inner + S * (n_c * outer);
+    T w[R > 1 ? R - 1 : 1], u0;
+#pragma unroll
+    for (int j = 1; j < R; ++j) w[j - 1] = c0 > 0 ? f[S * ((long long)(c0 - 1) * R + j)] : T(0);
+    u0 = f[S * ((long long)c0 * R)];
+    if (c0 == 0 && (flags & CF_LO_F)) u0 = T(0);
+    for (int c = c0; c < c1; ++c) {
+      const bool first = c == 0, last = c == ncell - 1;
+      T u[R + 1];
+      u[0] = u0;
+#pragma unroll
+      for (int j = 1; j <= R; ++j) u[j] = f[S * ((long long)c * R + j)];
+      if (last && (flags & CF_HI_F)) u[R] = T(0);
+#pragma unroll
+      for (int a = 0; a <= PC; ++a) {
+        if (a == PC && !last) break;
+        T v = T(0);
+#pragma unroll
+        for (int j = (a == PC ? 1 : 0); j <= (a == 0 ? R - 1 : R); ++j) v += m.L[j * (PC + 1) + a] * u[j];
+        if (a == 0) {
+#pragma unroll
+          for (int j = 1; j < R; ++j) v += m.L[j * (PC + 1) + PC] * w[j - 1];
+        }
+        const bool constrained = (first && a == 0 && (flags & CF_LO_C)) || (last && a == PC && (flags & CF_HI_C));
+        T *q = o + S * ((long long)c * PC + a);
+        if (add) {
+          if (!constrained) *q += v;
+        } else *q = constrained ? T(0) : v;
+      }
+#pragma unroll
+      for (int j = 1; j < R; ++j) w[j - 1] = u[j];
+      u0 = u[R];
+    }
+  }
+}
+
 template <typename TD, typename TS> __global__ void convert_kernel(TD *__restrict__ d, const TS *__restrict__ s, long long n)
 {
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) d[t] = TD(s[t]);
@@ -260,6 +311,12 @@ int launch_axis(T *out, const T *in, const int dims[3], int axis, const Band &b,
 }
 
 
+// restriction as a march along the axis with at most this many segments per line (0: one thread per coarse cell); STFEM_TRANSFER_MARCH
+static int march_segments = [] {
+  const char *e = getenv("STFEM_TRANSFER_MARCH");
+  return e ? atoi(e) : 64;
+}();
+
 template <typename T, int PC, int R>
 int launch_cell_t(bool prolongate, T *out, const T *in, long long S, int ncell, long long total, const double *L, int flags, int add, hipStream_t s)
 {
@@ -267,7 +324,15 @@ int launch_cell_t(bool prolongate, T *out, const T *in, long long S, int ncell, 
   for (int i = 0; i < 9 * 5; ++i) m.L[i] = T(L[i]);
   const int blocks = int(std::min<long long>((total + 255) / 256, 1 << 20));
   if (prolongate) cell_prolongate_kernel<T, PC, R><<<blocks, 256, 0, s>>>(out, in, S, ncell, total, m, flags, add);
-  else cell_restrict_kernel<T, PC, R><<<blocks, 256, 0, s>>>(out, in, S, ncell, total, m, flags, add);
+  else if (march_segments > 0) {
+    // enough threads to fill the chip: lines x segments >= ~2^18
+    const long long lines = total / ncell;
+    int nseg = int(std::min<long long>(ncell, std::max<long long>(1, (262144 + lines - 1) / lines)));
+    nseg = std::min(nseg, march_segments);
+    const long long tot = lines * nseg;
+    const int bl = int(std::min<long long>((tot + 255) / 256, 1 << 20));
+    cell_restrict_march_kernel<T, PC, R><<<bl, 256, 0, s>>>(out, in, S, ncell, nseg, tot, m, flags, add);
+  } else cell_restrict_kernel<T, PC, R><<<blocks, 256, 0, s>>>(out, in, S, ncell, total, m, flags, add);
   TR_TRY(hipGetLastError());
   return STFEM_OK;
 }
