@@ -628,7 +628,7 @@ template <int dim, typename Number> struct STMGHierarchy {
   STMGHierarchy(const Mesh &fine_mesh, unsigned fe_degree_space, const std::vector<unsigned> &poly_space_sequence, TimeStepType type, double time_step_size,
                 unsigned n_timesteps_at_once, const std::vector<MGType> &mg_type_level_, const std::vector<unsigned> &poly_time_sequence_,
                 const PreconditionerGMGAdditionalData &mg_data, CoarseningType coarsening_type, bool time_before_space, bool space_time_level_first,
-                bool wave = false)
+                bool wave = false, const std::function<void(Operator &, const Mesh &)> &evaluate_coefficient = {})
     : mg_type_level(mg_type_level_), poly_time_sequence(poly_time_sequence_)
   {
     const unsigned n_levels = unsigned(mg_type_level.size()) + 1;
@@ -651,6 +651,7 @@ template <int dim, typename Number> struct STMGHierarchy {
       if (new_space) {
         K[l] = std::make_shared<Operator>(mesh, degree, 0.0, 1.0);
         M[l] = std::make_shared<Operator>(*K[l], 1.0, 0.0);
+        if (evaluate_coefficient) evaluate_coefficient(*K[l], mesh); // K_mf_->evaluate_coefficient(coeff) on every level (tests/tp_01.cc:273-274)
       } else {
         K[l] = K[l + 1];
         M[l] = M[l + 1];

@@ -48,7 +48,21 @@ int main(int argc_all, char **argv_all)
   try {
     Mesh mesh;
     mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = n;
+    // coef=1: BASELINE configs[3] - the domain [-1, 1]^3 with the reference's discontinuous Coefficient(1, 9, 16) (operators.h:870-965; 5 subdivisions as
+    // tests/tp_01.cc sets them for it) on the Laplace operator of every level.  The manufactured solution is then no solution any more: the error columns
+    // only say that two runs solved the same systems; the run is about the solver (per-cell Vanka blocks, multigrid with the coefficient on every level).
+    const bool with_coef = option("coef", "0") == "1";
+    auto coefficient_of = [](const Mesh &m) {
+      std::vector<double> verts(size_t(m.ncell[0] + 1) * (m.ncell[1] + 1) * (m.ncell[2] + 1) * 3), values(size_t(m.ncell[0]) * m.ncell[1] * m.ncell[2]);
+      check(stfem_mesh_vertices(m.ncell, m.lower, m.upper, 0.0, 5489, 0, m.ncell[2], verts.data()), "stfem_mesh_vertices");
+      const int32_t sub[3] = {5, 5, 5};
+      check(stfem_coefficient_per_cell(m.ncell, verts.data(), 1.0, 9.0, 16.0, 0.0, sub, m.lower, m.upper, values.data()), "stfem_coefficient_per_cell");
+      return values;
+    };
+    if (with_coef)
+      for (int d = 0; d < 3; ++d) mesh.lower[d] = -1.0;
     MatrixFreeOperatorScalar<3, Number> K_mf(mesh, fe_degree, 0.0, 1.0), M_mf(K_mf, 1.0, 0.0);
+    if (with_coef) K_mf.evaluate_coefficient(coefficient_of(mesh));
     auto [Alpha_1, Beta_1, Gamma_1, Zeta_1] = get_fe_time_weights<Number>(type, k, tau, 1);
     // tests/tp_01.cc:143-158: slab matrices of the second-order system with the velocity eliminated
     auto [Alpha, Beta, rhs_uK, rhs_uM, rhs_vM] = get_fe_time_weights_wave<Number>(type, k, tau, nsteps);
@@ -131,7 +145,12 @@ int main(int argc_all, char **argv_all)
       std::fprintf(stderr, "\n");
       auto with = [&](auto number_tag) {
         using NP = decltype(number_tag);
-        STMGHierarchy<3, NP> mg(mesh, fe_degree, poly_space, type, tau, nsteps, mg_type_level, poly_time, mg_data, ctype, false, true, /*wave*/ true);
+        std::function<void(MatrixFreeOperatorScalar<3, NP> &, const Mesh &)> level_coef;
+        if (with_coef) level_coef = [&](MatrixFreeOperatorScalar<3, NP> &K, const Mesh &m) { K.evaluate_coefficient(coefficient_of(m)); };
+        STMGHierarchy<3, NP> mg(mesh, fe_degree, poly_space, type, tau, nsteps, mg_type_level, poly_time, mg_data, ctype, false, true, /*wave*/ true, level_coef);
+        for (unsigned l = 0; l < mg.operators.size(); ++l)
+          std::fprintf(stderr, "level %u: %llu x %u dofs, smoother %u, relaxation %.4f\n", l, (unsigned long long)mg.K[l]->m(), mg.fetw_w[l][0].m(),
+                       mg.gmg->smoother_types()[l], mg.gmg->relaxation(l));
         using P = GMG<3, NP, typename STMGHierarchy<3, NP>::System>;
         TimeIntegratorWave<Number, SystemN, SystemN, P> step(type, k, Alpha_1, Beta_1, Gamma_1, Zeta_1, 1e-12, matrix, *mg.gmg, rhs_matrix, rhs_matrix_v, source,
                                                              nsteps, true, max_steps);

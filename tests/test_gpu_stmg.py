@@ -226,3 +226,22 @@ def test_wave_driver_with_stmg(ttype, k, refinement, nsteps, extra):
     got = np.array([float(l8), float(l2), float(h1)])
     assert np.allclose(got, np.array(want), rtol=1e-7, atol=1e-10), (got, want)
     assert float(its) <= 30, res.stderr
+
+
+def test_wave_driver_with_coefficient_multigrid_vs_vanka_sweeps():
+    """BASELINE configs[3] in small: wave equation, dG(2) x Q3 on [-1,1]^3 with the discontinuous Coefficient(1,9,16) on every level (one Vanka
+    block per cell, built on the device).  Multigrid-preconditioned and Vanka-sweep-preconditioned FGMRES solve the same slab systems."""
+    exe = os.path.join(HOST, "wave_convergence")
+    rows = []
+    for pre in (["mg=1"], ["2"]):
+        res = subprocess.run([exe, "1", "2", "3", "1", *pre, "coef=1"] if pre == ["mg=1"] else [exe, "1", "2", "3", "1", "2", "0.5", "3", "10", "0.25", "coef=1"],
+                             capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout + res.stderr
+        rows.append([float(x) for x in res.stdout.split()])
+    # (the first run uses the default mesh of refinement 3 = 8 cells per direction; give both the same mesh)
+    res = subprocess.run([exe, "1", "2", "3", "1", "2", "0.5", "3", "10", "0.25", "mg=1", "coef=1"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    mg = [float(x) for x in res.stdout.split()]
+    assert mg[0] == rows[1][0] == 1000
+    assert np.allclose(mg[3:6], rows[1][3:6], rtol=1e-7, atol=1e-11), (mg, rows[1])
+    assert mg[6] <= rows[1][6] + 1e-9  # the multigrid needs no more iterations than the sweeps
