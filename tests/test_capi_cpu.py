@@ -73,6 +73,8 @@ def test_multigrid_entry_points_reject_bad_arguments(stfem):
     assert L.stfem_time_prolongation_matrix(0, 2, 3, None, dims) < 0           # steps per slab not a power of two
     assert L.stfem_time_projection_matrix(0, 0, 1, 1, None, dims) < 0          # cG(0) does not exist
     assert L.stfem_transfer_create(None, None, None) == -1
+    assert L.stfem_transfer_create_partitioned(None, None, 32, None) == -1
+    assert L.stfem_vanka_create_partitioned(None, 1, None, None, 16, None) == -1
     assert L.stfem_transfer_prolongate(None, None, None, 0, None) == -1
     assert L.stfem_transfer_line_matrices(3, 2, 2, 2, None, None) == -1        # 3 fine cells on 2 coarse ones
     assert L.stfem_transfer_line_matrices(4, 1, 2, 2, None, None) == -1        # fine degree below the coarse one
