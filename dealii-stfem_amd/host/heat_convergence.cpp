@@ -126,6 +126,7 @@ int main(int argc_all, char **argv_all)
       mg_data.relaxation = std::atof(option("relaxation", "0").c_str());
       mg_data.variable = option("variable", "1") == "1";
       mg_data.smoothing_steps = std::atoi(option("steps", "1").c_str());
+      if (option("smoother", "relaxation") == "chebyshev") mg_data.smoother = SupportedSmoothers::Chebyshev; // steps = its degree
       std::fprintf(stderr, "levels:");
       for (auto m : mg_type_level) std::fprintf(stderr, " %c", char(m));
       std::fprintf(stderr, "\n");
