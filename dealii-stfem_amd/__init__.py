@@ -95,6 +95,8 @@ SIGNATURES = {
     "stfem_quadrature_points": (C.c_int, [_vp, C.c_int, _dp]),
     "stfem_integrate_rhs": (C.c_int, [_vp, C.c_int, _dp, _vp, C.c_int, _vp]),
     "stfem_integrate_difference": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _dp, _dp, _dp, _vp]),
+    "stfem_integrate_rhs_product": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, _vp, C.c_int, _vp]),
+    "stfem_integrate_difference_product": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _dp, _vp]),
     "stfem_vector_axpby": (C.c_int, [_vp, C.c_double, _vp, C.c_double, _vp, _vp]),
     "stfem_driver_last_error": (C.c_char_p, []),
     "stfem_gauss_rule": (C.c_int, [C.c_int, _dp, _dp]),

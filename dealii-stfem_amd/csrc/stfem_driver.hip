@@ -94,9 +94,41 @@ __device__ double det3(const double J[3][3])
          J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
 }
 
+// the trilinear map of the reference point xi in cell (cx, cy, cz)
+__device__ void map_point_dev(const CellGeomParams &g, int cx, int cy, int cz, const double xi[3], double x[3])
+{
+  const long long nvx = g.ncx + 1, nvy = g.ncy + 1;
+  x[0] = x[1] = x[2] = 0.0;
+  for (int k = 0; k < 2; ++k)
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 2; ++i) {
+        const double w = (i ? xi[0] : 1 - xi[0]) * (j ? xi[1] : 1 - xi[1]) * (k ? xi[2] : 1 - xi[2]);
+        const double *V = g.vertices + 3 * ((cx + i) + nvx * ((cy + j) + nvy * (long long)(cz + k)));
+        for (int d = 0; d < 3; ++d) x[d] += w * V[d];
+      }
+}
+
+// f(x) = amplitude * prod_d sin(2 pi frequency x_d): the separable functions of the reference's convergence tests (exact solutions and
+// right-hand sides of include/exact_solution.h:27-81, 147-197 at a fixed time), evaluated on the device instead of handed in point by point
+struct ProductFn {
+  int on;
+  double amplitude, frequency;
+};
+__device__ double product_value(const ProductFn &f, const double x[3], double grad[3])
+{
+  const double w = 6.283185307179586476925286766559 * f.frequency;
+  const double s[3] = {sin(w * x[0]), sin(w * x[1]), sin(w * x[2])}, c[3] = {cos(w * x[0]), cos(w * x[1]), cos(w * x[2])};
+  if (grad) {
+    grad[0] = f.amplitude * w * c[0] * s[1] * s[2];
+    grad[1] = f.amplitude * w * s[0] * c[1] * s[2];
+    grad[2] = f.amplitude * w * s[0] * s[1] * c[2];
+  }
+  return f.amplitude * s[0] * s[1] * s[2];
+}
+
 // rhs_a += sum_q JxW_q f_q phi_a(x_q); one workgroup per cell; constrained rows stay 0
 template <typename T>
-__global__ __launch_bounds__(256) void integrate_rhs_kernel(const CellGeomParams g, const double *__restrict__ fq, T *__restrict__ dst)
+__global__ __launch_bounds__(256) void integrate_rhs_kernel(const CellGeomParams g, const double *__restrict__ fq, T *__restrict__ dst, const ProductFn pf)
 {
   extern __shared__ double sm[]; // [nq^3] JxW f
   const int n = g.p + 1, nq = g.nq, nq3 = nq * nq * nq, nloc = n * n * n;
@@ -107,7 +139,13 @@ __global__ __launch_bounds__(256) void integrate_rhs_kernel(const CellGeomParams
     const double xi[3] = {g.xq[qx], g.xq[qy], g.xq[qz]};
     double J[3][3];
     jacobian(g, cx, cy, cz, xi, J);
-    sm[q] = det3(J) * g.wq[qx] * g.wq[qy] * g.wq[qz] * fq[cell * nq3 + q];
+    double fv;
+    if (pf.on) {
+      double x[3];
+      map_point_dev(g, cx, cy, cz, xi, x);
+      fv = product_value(pf, x, nullptr);
+    } else fv = fq[cell * nq3 + q];
+    sm[q] = det3(J) * g.wq[qx] * g.wq[qy] * g.wq[qz] * fv;
   }
   __syncthreads();
   for (int a = threadIdx.x; a < nloc; a += 256) {
@@ -130,7 +168,7 @@ __global__ __launch_bounds__(256) void integrate_rhs_kernel(const CellGeomParams
 template <typename T>
 __global__ __launch_bounds__(256) void integrate_difference_kernel(const CellGeomParams g, const T *__restrict__ u,
                                                                    const double *__restrict__ exact, const double *__restrict__ exact_grad,
-                                                                   double *__restrict__ out)
+                                                                   double *__restrict__ out, const ProductFn pf)
 {
   extern __shared__ double sm[]; // [nloc] cell values, then 3 x 256 reduction
   const int n = g.p + 1, nq = g.nq, nq3 = nq * nq * nq, nloc = n * n * n;
@@ -160,10 +198,20 @@ __global__ __launch_bounds__(256) void integrate_difference_kernel(const CellGeo
           gr[1] += w * sx * g.D[qy * n + ay] * sz;
           gr[2] += w * sx * sy * g.D[qz * n + az];
         }
-    const double e = val - exact[cell * nq3 + q];
+    double ex, exg[3] = {0, 0, 0};
+    if (pf.on) {
+      double x[3];
+      map_point_dev(g, cx, cy, cz, xi, x);
+      ex = product_value(pf, x, exg);
+    } else {
+      ex = exact[cell * nq3 + q];
+      if (exact_grad)
+        for (int d = 0; d < 3; ++d) exg[d] = exact_grad[(cell * nq3 + q) * 3 + d];
+    }
+    const double e = val - ex;
     l2 += JxW * e * e;
     l8 = fmax(l8, fabs(e));
-    if (exact_grad) {
+    if (exact_grad || pf.on) {
       // physical gradient = J^-T reference gradient
       const double id = 1.0 / det;
       double Ji[3][3];
@@ -173,7 +221,7 @@ __global__ __launch_bounds__(256) void integrate_difference_kernel(const CellGeo
       Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id; Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
       Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
       for (int d = 0; d < 3; ++d) {
-        const double gd = gr[0] * Ji[0][d] + gr[1] * Ji[1][d] + gr[2] * Ji[2][d] - exact_grad[(cell * nq3 + q) * 3 + d];
+        const double gd = gr[0] * Ji[0][d] + gr[1] * Ji[1][d] + gr[2] * Ji[2][d] - exg[d];
         h1 += JxW * gd * gd;
       }
     }
@@ -273,9 +321,9 @@ int stfem_quadrature_points(const stfem_ctx *c, int nq, double *out)
   return STFEM_OK;
 }
 
-int stfem_integrate_rhs(stfem_ctx *c, int nq, const double *f_at_points, stfem_vec *dst, int block, void *stream)
+static int integrate_rhs_impl(stfem_ctx *c, int nq, const double *f_at_points, const ProductFn pf, stfem_vec *dst, int block, void *stream)
 {
-  if (!c || !f_at_points || !dst || dst->ctx != c || block < 0 || block >= dst->nb || nq < 1 || nq > 8) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!c || (!f_at_points && !pf.on) || !dst || dst->ctx != c || block < 0 || block >= dst->nb || nq < 1 || nq > 8) return STFEM_ERR_INVALID_ARGUMENT;
   DRV_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   GeomUpload geo;
@@ -283,19 +331,22 @@ int stfem_integrate_rhs(stfem_ctx *c, int nq, const double *f_at_points, stfem_v
   if (rc != STFEM_OK) return rc;
   const size_t nf = size_t(c->ncells) * nq * nq * nq;
   double *d_f = nullptr;
-  if (hipMalloc(&d_f, nf * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
-  hipError_t e = hipMemcpyAsync(d_f, f_at_points, nf * sizeof(double), hipMemcpyHostToDevice, st);
+  hipError_t e = hipSuccess;
+  if (!pf.on) {
+    if (hipMalloc(&d_f, nf * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+    e = hipMemcpyAsync(d_f, f_at_points, nf * sizeof(double), hipMemcpyHostToDevice, st);
+  }
   if (e == hipSuccess) e = hipMemsetAsync(dst->blk[block], 0, size_t(c->ndofs) * c->es, st);
   if (e == hipSuccess) {
     const size_t lds = size_t(nq) * nq * nq * sizeof(double);
     if (c->prec)
-      hipLaunchKernelGGL(integrate_rhs_kernel<float>, dim3((unsigned)c->ncells), dim3(256), lds, st, geo.g, d_f, static_cast<float *>(dst->blk[block]));
+      hipLaunchKernelGGL(integrate_rhs_kernel<float>, dim3((unsigned)c->ncells), dim3(256), lds, st, geo.g, d_f, static_cast<float *>(dst->blk[block]), pf);
     else
-      hipLaunchKernelGGL(integrate_rhs_kernel<double>, dim3((unsigned)c->ncells), dim3(256), lds, st, geo.g, d_f, static_cast<double *>(dst->blk[block]));
+      hipLaunchKernelGGL(integrate_rhs_kernel<double>, dim3((unsigned)c->ncells), dim3(256), lds, st, geo.g, d_f, static_cast<double *>(dst->blk[block]), pf);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_f);
+  if (d_f) (void)hipFree(d_f);
   if (e != hipSuccess) {
     snprintf(g_driver_err, sizeof(g_driver_err), "stfem_integrate_rhs: %s", hipGetErrorString(e));
     return STFEM_ERR_HIP;
@@ -303,10 +354,19 @@ int stfem_integrate_rhs(stfem_ctx *c, int nq, const double *f_at_points, stfem_v
   return STFEM_OK;
 }
 
-int stfem_integrate_difference(stfem_ctx *c, int nq, const stfem_vec *u, int block, const double *exact_at_points,
-                               const double *exact_grad_at_points, double out[3], void *stream)
+int stfem_integrate_rhs(stfem_ctx *c, int nq, const double *f_at_points, stfem_vec *dst, int block, void *stream)
 {
-  if (!c || !u || u->ctx != c || block < 0 || block >= u->nb || !exact_at_points || !out || nq < 1 || nq > 8)
+  return integrate_rhs_impl(c, nq, f_at_points, ProductFn{0, 0.0, 0.0}, dst, block, stream);
+}
+int stfem_integrate_rhs_product(stfem_ctx *c, int nq, double amplitude, double frequency, stfem_vec *dst, int block, void *stream)
+{
+  return integrate_rhs_impl(c, nq, nullptr, ProductFn{1, amplitude, frequency}, dst, block, stream);
+}
+
+static int integrate_difference_impl(stfem_ctx *c, int nq, const stfem_vec *u, int block, const double *exact_at_points,
+                                     const double *exact_grad_at_points, const ProductFn pf, double out[3], void *stream)
+{
+  if (!c || !u || u->ctx != c || block < 0 || block >= u->nb || (!exact_at_points && !pf.on) || !out || nq < 1 || nq > 8)
     return STFEM_ERR_INVALID_ARGUMENT;
   DRV_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -320,23 +380,24 @@ int stfem_integrate_difference(stfem_ctx *c, int nq, const stfem_vec *u, int blo
     if (d_g) (void)hipFree(d_g);
     if (d_out) (void)hipFree(d_out);
   };
-  if (hipMalloc(&d_e, npts * sizeof(double)) != hipSuccess || hipMalloc(&d_out, size_t(c->ncells) * 3 * sizeof(double)) != hipSuccess ||
-      (exact_grad_at_points && hipMalloc(&d_g, npts * 3 * sizeof(double)) != hipSuccess)) {
+  if ((!pf.on && hipMalloc(&d_e, npts * sizeof(double)) != hipSuccess) || hipMalloc(&d_out, size_t(c->ncells) * 3 * sizeof(double)) != hipSuccess ||
+      (!pf.on && exact_grad_at_points && hipMalloc(&d_g, npts * 3 * sizeof(double)) != hipSuccess)) {
     cleanup();
     return STFEM_ERR_OUT_OF_MEMORY;
   }
-  hipError_t e = hipMemcpyAsync(d_e, exact_at_points, npts * sizeof(double), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess && exact_grad_at_points) e = hipMemcpyAsync(d_g, exact_grad_at_points, npts * 3 * sizeof(double), hipMemcpyHostToDevice, st);
+  hipError_t e = hipSuccess;
+  if (!pf.on) e = hipMemcpyAsync(d_e, exact_at_points, npts * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && !pf.on && exact_grad_at_points) e = hipMemcpyAsync(d_g, exact_grad_at_points, npts * 3 * sizeof(double), hipMemcpyHostToDevice, st);
   std::vector<double> part(size_t(c->ncells) * 3);
   if (e == hipSuccess) {
     const int n = c->p + 1;
     const size_t lds = (size_t(n) * n * n + 3 * 256) * sizeof(double);
     if (c->prec)
       hipLaunchKernelGGL(integrate_difference_kernel<float>, dim3((unsigned)c->ncells), dim3(256), lds, st, geo.g,
-                         static_cast<const float *>(u->blk[block]), d_e, d_g, d_out);
+                         static_cast<const float *>(u->blk[block]), d_e, d_g, d_out, pf);
     else
       hipLaunchKernelGGL(integrate_difference_kernel<double>, dim3((unsigned)c->ncells), dim3(256), lds, st, geo.g,
-                         static_cast<const double *>(u->blk[block]), d_e, d_g, d_out);
+                         static_cast<const double *>(u->blk[block]), d_e, d_g, d_out, pf);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_out, part.size() * sizeof(double), hipMemcpyDeviceToHost, st);
@@ -353,6 +414,17 @@ int stfem_integrate_difference(stfem_ctx *c, int nq, const stfem_vec *u, int blo
     out[2] += part[cell * 3 + 2];
   }
   return STFEM_OK;
+}
+
+int stfem_integrate_difference(stfem_ctx *c, int nq, const stfem_vec *u, int block, const double *exact_at_points,
+                               const double *exact_grad_at_points, double out[3], void *stream)
+{
+  return integrate_difference_impl(c, nq, u, block, exact_at_points, exact_grad_at_points, ProductFn{0, 0.0, 0.0}, out, stream);
+}
+int stfem_integrate_difference_product(stfem_ctx *c, int nq, const stfem_vec *u, int block, double amplitude, double frequency, double out[3],
+                                       void *stream)
+{
+  return integrate_difference_impl(c, nq, u, block, nullptr, nullptr, ProductFn{1, amplitude, frequency}, out, stream);
 }
 
 int stfem_gauss_rule(int n, double *points, double *weights)

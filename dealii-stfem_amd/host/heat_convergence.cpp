@@ -96,7 +96,12 @@ int main(int argc_all, char **argv_all)
 
     double l2 = 0.0, l8 = -1.0, h1 = 0.0, time = 0.0, rhs_s = 0.0, solve_s = 0.0;
     unsigned total_its = 0, solves = 0;
+    // host_functions=1: the source and the exact solution evaluated on the host at the quadrature points (the general interface: any function);
+    // default: as separable functions on the device
+    const bool on_device = option("host_functions", "0") != "1";
+    if (on_device) error_calculator.exact_product = ProductFunction{f, [&](double t) { return std::sin(2 * PI * f * t); }};
     auto run = [&](auto &step) {
+      if (on_device) step.source_product = ProductFunction{f, [&](double t) { return 3 * 4 * PI * PI * f * f * std::sin(2 * PI * f * t) + 2 * PI * f * std::cos(2 * PI * f * t); }};
       while (time < end_time - 1e-12) {
         step.solve(x, prev_x, rhs, time, tau);
         rhs_s = step.assemble_seconds;
@@ -152,8 +157,8 @@ int main(int argc_all, char **argv_all)
       TimeIntegratorFO<Number, SystemN, SystemN, PreconditionIdentity> step(type, k, Alpha_1, Gamma_1, 1e-12, matrix, precond, rhs_matrix, source, nsteps, true, 1e-12, max_steps);
       run(step);
     }
-    std::fprintf(stderr, "%u slab solves: right-hand sides %.3f s (source evaluated on the host), FGMRES %.3f s for %u iterations = %.2f ms per iteration\n",
-                 solves, rhs_s, solve_s, total_its, 1e3 * solve_s / std::max(1u, total_its));
+    std::fprintf(stderr, "%u slab solves: right-hand sides %.3f s (source evaluated on the %s), FGMRES %.3f s for %u iterations = %.2f ms per iteration\n",
+                 solves, rhs_s, on_device ? "device" : "host", solve_s, total_its, 1e3 * solve_s / std::max(1u, total_its));
     std::printf("%d %llu %u %.12e %.12e %.12e %.2f\n", n * n * n, (unsigned long long)K_mf.m(), x.n_blocks(), l8, std::sqrt(l2), std::sqrt(h1),
                 double(total_its) / solves);
   } catch (const std::exception &e) {

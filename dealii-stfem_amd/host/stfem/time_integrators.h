@@ -203,6 +203,15 @@ inline std::vector<double> time_points(TimeStepType type, unsigned r)
   return p;
 }
 
+// A separable function amplitude(t) * prod_d sin(2 pi frequency x_d) - the exact solutions and right-hand sides of the reference's
+// convergence tests (include/exact_solution.h:27-81, 147-197) - is evaluated on the device (stfem_integrate_rhs_product,
+// stfem_integrate_difference_product): no point list, no host evaluation, no upload
+struct ProductFunction {
+  double frequency = 1.0;
+  std::function<double(double)> amplitude; // of t
+  explicit operator bool() const { return bool(amplitude); }
+};
+
 // A scalar function of (x, t) evaluated at a list of points: out[i] = f(points[3 i .. 3 i + 2], t)
 using PointFunction = std::function<void(double time, const std::vector<double> &points, std::vector<double> &out)>;
 
@@ -222,9 +231,8 @@ public:
     if (const char *e = std::getenv("STFEM_FGMRES_VERBOSE")) solver.verbose = unsigned(std::atoi(e));
     const Context &c = *matrix_context();
     nq = int(c.degree) + 1; // QGauss(fe degree + 1): the operator's rule (tests/tp_01.cc:95)
-    qpoints.resize(size_t(stfem_n_cells(c.h)) * nq * nq * nq * 3);
-    check(stfem_quadrature_points(c.h, nq, qpoints.data()), "stfem_quadrature_points");
   }
+  ProductFunction source_product; // if set: the source as a separable function on the device instead of `source` at the points
 
   // assemble_force (time_integrators.h:73-111): Alpha is diagonal (time quadrature = support points)
   void assemble_force(V &rhs, double time, double time_step) const
@@ -235,8 +243,17 @@ public:
     for (unsigned it = 0; it < n_timesteps_at_once; ++it)
       for (unsigned j = 0; j < quad_time.size(); ++j) {
         const double t = time + time_step * it + time_step * quad_time[j];
-        source(t, qpoints, fq);
-        check(stfem_integrate_rhs(rhs.context()->h, nq, fq.data(), tmp.handle(), 0, nullptr), "stfem_integrate_rhs");
+        if (source_product) {
+          check(stfem_integrate_rhs_product(rhs.context()->h, nq, source_product.amplitude(t), source_product.frequency, tmp.handle(), 0, nullptr),
+                "stfem_integrate_rhs_product");
+        } else {
+          if (qpoints.empty()) {
+            qpoints.resize(size_t(stfem_n_cells(rhs.context()->h)) * nq * nq * nq * 3);
+            check(stfem_quadrature_points(rhs.context()->h, nq, qpoints.data()), "stfem_quadrature_points");
+          }
+          source(t, qpoints, fq);
+          check(stfem_integrate_rhs(rhs.context()->h, nq, fq.data(), tmp.handle(), 0, nullptr), "stfem_integrate_rhs");
+        }
         auto add = [&](unsigned block, double w) {
           V view = block_view(rhs, block);
           axpby(w, tmp, 1.0, view);
@@ -287,7 +304,7 @@ protected:
   unsigned n_timesteps_at_once, nt_dofs;
   bool do_extrapolate;
   int nq = 0;
-  std::vector<double> qpoints;
+  mutable std::vector<double> qpoints;
 };
 
 // include/time_integrators.h:343-459: the wave equation as a first-order system with the velocity eliminated from the
@@ -363,10 +380,9 @@ public:
       nodes(time_points(type, time_degree)), tq(time_degree + 1), tw(time_degree + 1)
   {
     check(stfem_gauss_rule(int(time_degree + 1), tq.data(), tw.data()), "stfem_gauss_rule");
-    qpoints.resize(size_t(stfem_n_cells(ctx->h)) * nq * nq * nq * 3);
-    check(stfem_quadrature_points(ctx->h, nq, qpoints.data()), "stfem_quadrature_points");
     numeric.reinit(ctx, 1);
   }
+  ProductFunction exact_product; // if set: the exact solution (and its gradient) as a separable function on the device
   // returns {L2^2 contribution, Linfty, H1-semi^2 contribution} of the slab [time, time + n_steps * time_step]
   std::array<double, 3> evaluate_error(double time, double time_step, const V &x, const V &prev_x, unsigned n_time_steps_at_once)
   {
@@ -386,10 +402,19 @@ public:
           else axpby(L[0], block_view(x, nt_dofs * it - 1), 1.0, numeric);
           for (unsigned i = 1; i <= time_degree; ++i) axpby(L[i], block_view(x, it * nt_dofs + i - 1), 1.0, numeric);
         }
-        exact(t, qpoints, ue);
-        exact_gradient(t, qpoints, ge);
         double out[3];
-        check(stfem_integrate_difference(ctx->h, nq, numeric.handle(), 0, ue.data(), ge.data(), out, nullptr), "stfem_integrate_difference");
+        if (exact_product) {
+          check(stfem_integrate_difference_product(ctx->h, nq, numeric.handle(), 0, exact_product.amplitude(t), exact_product.frequency, out, nullptr),
+                "stfem_integrate_difference_product");
+        } else {
+          if (qpoints.empty()) {
+            qpoints.resize(size_t(stfem_n_cells(ctx->h)) * nq * nq * nq * 3);
+            check(stfem_quadrature_points(ctx->h, nq, qpoints.data()), "stfem_quadrature_points");
+          }
+          exact(t, qpoints, ue);
+          exact_gradient(t, qpoints, ge);
+          check(stfem_integrate_difference(ctx->h, nq, numeric.handle(), 0, ue.data(), ge.data(), out, nullptr), "stfem_integrate_difference");
+        }
         err[0] += time_step * tw[q] * out[0];
         err[1] = std::max(err[1], out[1]);
         err[2] += time_step * tw[q] * out[2];

@@ -297,6 +297,11 @@ int stfem_quadrature_points(const stfem_ctx *ctx, int nq, double *out);
 int stfem_integrate_rhs(stfem_ctx *ctx, int nq, const double *f_at_points, stfem_vec *dst, int block, void *stream);
 int stfem_integrate_difference(stfem_ctx *ctx, int nq, const stfem_vec *u, int block, const double *exact_at_points,
                                const double *exact_grad_at_points, double out[3], void *stream);
+/* the same two with f(x) = amplitude * prod_d sin(2 pi frequency x_d) - the separable right-hand sides and exact solutions of the reference's
+ * convergence tests (include/exact_solution.h:27-81, 147-197) at a fixed time - evaluated on the device: nothing crosses the host */
+int stfem_integrate_rhs_product(stfem_ctx *ctx, int nq, double amplitude, double frequency, stfem_vec *dst, int block, void *stream);
+int stfem_integrate_difference_product(stfem_ctx *ctx, int nq, const stfem_vec *u, int block, double amplitude, double frequency, double out[3],
+                                       void *stream);
 int stfem_vector_axpby(stfem_ctx *ctx, double a, const stfem_vec *x, double b, stfem_vec *y, void *stream);
 const char *stfem_driver_last_error(void);
 /* QGauss(n) on [0, 1]; the support points of the temporal basis, get_time_quad (fe_time.cc:152-161): QGaussLobatto(r + 1)
