@@ -35,6 +35,7 @@
 namespace {
 
 constexpr int MAXOUT = 8;
+constexpr int MAXSRC = 4; // sources / destination pairs of the fused form
 
 struct StokesParams {
   const double *vertices; // device, (nc+1)^3 * 3
@@ -49,6 +50,11 @@ struct StokesParams {
   double wKu[MAXOUT], wKp[MAXOUT], wM[MAXOUT];
   double Su[9], Du[9], Sp[6]; // [q*3+a], [q*3+a], [q*2+a]
   double xq[3], wq[3];
+  // fused form (SystemMatrixStokes::vmult with up to MAXSRC source time dofs and up to MAXSRC destination pairs in ONE set of colour
+  // launches): the cell is evaluated for every source in turn, the weighted results are summed in registers and scattered once
+  int nsrc;                   // 0 / 1: the single source u, p with the weights above
+  const double *us[4], *ps[4];
+  double fKu[4][4], fKp[4][4], fM[4][4]; // [destination pair][source]
   int colour;                 // this launch handles the cells with (cx & 1) + 2 (cy & 1) + 4 (cz & 1) == colour
   int store_u[MAXOUT], store_p[MAXOUT]; // 1: the first cell to touch a DoF (lowest colour) stores, the others add; 0: all add
   int cart;                   // axis-aligned uniform cells: constant diagonal Jacobian
@@ -78,7 +84,8 @@ __device__ __forceinline__ void wave_fence()
 //              lanes with a, b, c < 2 also carry the pressure node (a, b, c)
 // The lane's rows / columns of the 1D tables stay in registers for the whole kernel.
 // CART: axis-aligned uniform cells (the context was created without vertices): constant diagonal Jacobian.
-template <bool CART>
+// FUSED: several sources per cell, weighted sums in registers, one scatter (prm.nsrc > 1; see StokesParams)
+template <bool CART, bool FUSED>
 __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm)
 {
   constexpr int RX = 351, RY = 351; // doubles per cell of the two regions (largest stage: 13 x 27)
@@ -137,18 +144,25 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     return q;
   };
   double un[3] = {0, 0, 0}, pn = 0.0;
-  auto fetch = [&](const CellIds &q) { // read_dof_values: constrained velocity entries read as 0
+  const int nsrc = FUSED ? prm.nsrc : 1;
+  auto fetch = [&](const CellIds &q, int s) { // read_dof_values: constrained velocity entries read as 0
+    const double *us = FUSED ? prm.us[s] : prm.u, *ps = FUSED ? prm.ps[s] : prm.p;
     if (q.ok && lane27 && !q.con) {
 #pragma unroll
-      for (int comp = 0; comp < 3; ++comp) un[comp] = prm.u[comp * prm.Nu + q.gu];
+      for (int comp = 0; comp < 3; ++comp) un[comp] = us[comp * prm.Nu + q.gu];
     } else {
       un[0] = un[1] = un[2] = 0.0;
     }
-    pn = (q.ok && pnode && prm.p) ? prm.p[q.gp] : 0.0;
+    pn = (q.ok && pnode && ps) ? ps[q.gp] : 0.0;
   };
   CellIds nxt = ids(first);
-  fetch(nxt);
-  for (long long it = 0; it < run; ++it) {
+  fetch(nxt, 0);
+  double accU[FUSED ? MAXSRC : 1][3], accP[FUSED ? MAXSRC : 1]; // fused form: sums over the sources, per destination pair
+#pragma unroll
+  for (int o = 0; o < (FUSED ? MAXSRC : 1); ++o) accU[o][0] = accU[o][1] = accU[o][2] = accP[o] = 0.0;
+  for (long long it2 = 0; it2 < run * nsrc; ++it2) {
+    const long long it = it2 / nsrc;
+    const int src = int(it2 - it * nsrc);
     const CellIds cur = nxt;
     const bool cell_ok = cur.ok;
     const int cx = cur.cx, cy = cur.cy, cz = cur.cz;
@@ -163,8 +177,8 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = un[comp];
     }
     if (pnode) X[81 + a + 2 * b + 4 * c] = pn;
-    nxt = ids(first + it + 1);
-    fetch(nxt);
+    nxt = ids(first + (it2 + 1) / nsrc);
+    fetch(nxt, int((it2 + 1) % nsrc));
     wave_fence();
 
     // ---- evaluate, x: (n_x, n_y, n_z) -> (q_x, n_y, n_z): values and x derivatives -> Y
@@ -307,13 +321,47 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
 
     // ---- distribute_local_to_global: constrained velocity rows stay 0.  A DoF on a face shared with a
     // neighbouring cell is first touched by the cell whose colour bits are 0 in all shared directions.
-    if (active) {
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int o = 0; o < MAXSRC; ++o)
+        if (o < prm.nout) {
+          const double kU = prm.fKu[o][src], kM = prm.fM[o][src];
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp) accU[o][comp] = fma(kU, rK[comp], fma(kM, rM[comp], accU[o][comp]));
+          accP[o] = fma(prm.fKp[o][src], rP, accP[o]);
+        }
+    }
+    if (active && src == nsrc - 1) {
       const bool fu = !((a == 0 && cx > 0 && px) || (a == 2 && cx < prm.ncx - 1 && px) ||
                         (b == 0 && cy > 0 && py) || (b == 2 && cy < prm.ncy - 1 && py) ||
                         (c == 0 && cz > 0 && pz) || (c == 2 && cz < prm.ncz - 1 && pz));
       const bool fp = !((a == 0 && cx > 0 && px) || (a == 1 && cx < prm.ncx - 1 && px) ||
                         (b == 0 && cy > 0 && py) || (b == 1 && cy < prm.ncy - 1 && py) ||
                         (c == 0 && cz > 0 && pz) || (c == 1 && cz < prm.ncz - 1 && pz));
+      if constexpr (FUSED) {
+#pragma unroll
+        for (int o = 0; o < MAXSRC; ++o)
+          if (o < prm.nout) {
+            if (prm.out_u[o]) {
+              double *d = prm.out_u[o] + gu;
+              if (prm.store_u[o] && fu) {
+#pragma unroll
+                for (int comp = 0; comp < 3; ++comp) d[comp * prm.Nu] = con ? 0.0 : accU[o][comp];
+              } else if (!con) {
+                double v[3];
+#pragma unroll
+                for (int comp = 0; comp < 3; ++comp) v[comp] = d[comp * prm.Nu];
+#pragma unroll
+                for (int comp = 0; comp < 3; ++comp) d[comp * prm.Nu] = v[comp] + accU[o][comp];
+              }
+            }
+            if (pnode && prm.out_p[o]) {
+              double *d = prm.out_p[o] + gp;
+              if (prm.store_p[o] && fp) *d = accP[o];
+              else *d += accP[o];
+            }
+          }
+      } else
       for (int j = 0; j < prm.nout; ++j) {
         if (prm.out_u[j]) {
           double *d = prm.out_u[j] + gu;
@@ -335,6 +383,10 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
           else *d += prm.wKp[j] * rP;
         }
       }
+    }
+    if (FUSED && src == nsrc - 1) {
+#pragma unroll
+      for (int o = 0; o < (FUSED ? MAXSRC : 1); ++o) accU[o][0] = accU[o][1] = accU[o][2] = accP[o] = 0.0;
     }
     wave_fence(); // the next cell's gather overwrites X
   }
@@ -514,8 +566,11 @@ static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
     // the workgroups walk over the cells; four times as many as are resident at once (two per CU) measured best:
     // 1.00 against 1.35 ms for the cG(2) system on 64^3 cells, no difference for cG(1)
     const unsigned grid = (unsigned)std::min<long long>((n + 7) / 8, (long long)c->n_cu * 8);
-    if (prm.cart) hipLaunchKernelGGL(stokes_cell_kernel<true>, dim3(grid), dim3(256), 0, st, prm);
-    else hipLaunchKernelGGL(stokes_cell_kernel<false>, dim3(grid), dim3(256), 0, st, prm);
+    if (prm.nsrc > 1) {
+      if (prm.cart) hipLaunchKernelGGL((stokes_cell_kernel<true, true>), dim3(grid), dim3(256), 0, st, prm);
+      else hipLaunchKernelGGL((stokes_cell_kernel<false, true>), dim3(grid), dim3(256), 0, st, prm);
+    } else if (prm.cart) hipLaunchKernelGGL((stokes_cell_kernel<true, false>), dim3(grid), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL((stokes_cell_kernel<false, false>), dim3(grid), dim3(256), 0, st, prm);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -577,6 +632,38 @@ int stfem_stokes_st_vmult(stfem_stokes_ctx *c, int n_timesteps_at_once, int n_ti
   // reaches are zeroed at the end
   std::vector<char> written(nb, 0);
   const double eps10 = 10 * std::numeric_limits<double>::epsilon(); // internal::scatter, operators.h:106
+  // up to MAXSRC time dofs: ONE set of colour launches - every cell is evaluated for all sources, the destinations are written once
+  static const bool fused_ok = [] {
+    const char *e = getenv("STFEM_STOKES_FUSED");
+    return !e || atoi(e) != 0;
+  }();
+  if (fused_ok && ns * nt >= 2 && ns * nt <= MAXSRC) {
+    StokesParams prm = c->base;
+    prm.nsrc = ns * nt;
+    prm.nout = ns * nt;
+    for (int it = 0; it < ns; ++it)
+      for (int id = 0; id < nt; ++id) {
+        const int sidx = it * nt + id, i = index(it, 0, id);
+        prm.us[sidx] = src_blocks[index(it, 0, id)];
+        prm.ps[sidx] = src_blocks[index(it, 1, id)];
+        for (int jt = 0; jt < ns; ++jt)
+          for (int jd = 0; jd < nt; ++jd) {
+            const int o = jt * nt + jd, ju = index(jt, 0, jd), jp = index(jt, 1, jd);
+            const double aU = Alpha[size_t(ju) * nb + i], aP = Alpha[size_t(jp) * nb + i], bU = Beta[size_t(ju) * nb + i];
+            prm.fKu[o][sidx] = std::abs(aU) > eps10 ? aU : 0.0; // entries below the threshold are skipped (operators.h:91-110)
+            prm.fKp[o][sidx] = std::abs(aP) > eps10 ? aP : 0.0;
+            prm.fM[o][sidx] = std::abs(bU) > eps10 ? bU : 0.0;
+          }
+      }
+    for (int jt = 0; jt < ns; ++jt)
+      for (int jd = 0; jd < nt; ++jd) {
+        const int o = jt * nt + jd;
+        prm.out_u[o] = dst_blocks[index(jt, 0, jd)];
+        prm.out_p[o] = dst_blocks[index(jt, 1, jd)];
+        prm.store_u[o] = prm.store_p[o] = 1; // dst = 0.0 + the sums: every destination is overwritten
+      }
+    return stokes_launch(c, prm, st);
+  }
   for (int it = 0; it < ns; ++it)
     for (int id = 0; id < nt; ++id) {
       const int i = index(it, 0, id); // the velocity column drives all scatters (operators.h:851-862)
