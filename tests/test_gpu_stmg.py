@@ -27,6 +27,9 @@ def rel(a, b):
     (4, (2, 3, 2), 2, (2, 3, 2), 63 & ~48, 0.1),  # p-transfer on a perturbed slab with open z faces
     (2, (4, 2, 2), 1, (2, 1, 1), 0, 0.0),       # hp at once, no constraints
     (1, (6, 4, 4), 1, (3, 2, 2), 63 & ~3, 0.12),  # Q1, perturbed
+    (4, (4, 2, 4), 3, (2, 1, 2), 63, 0.0),      # hp: Q4 on the fine cells, Q3 on the coarse ones (8 fine nodes per 3 coarse)
+    (3, (2, 4, 2), 2, (1, 2, 1), 63 & ~12, 0.0),  # hp: 6 fine nodes per 2 coarse, open y faces
+    (2, (4, 2, 4), 2, (2, 2, 2), 63, 0.0),      # semi-coarsening: the y direction keeps its cells and degree (a copy along y)
 ])
 def test_space_transfer_vs_oracle(pf, ncf, pc, ncc, mask, distort, number):
     from oracle import stmg_oracle
