@@ -52,6 +52,7 @@ struct StokesParams {
   double xq[3], wq[3];
   // fused form (SystemMatrixStokes::vmult with up to MAXSRC source time dofs and up to MAXSRC destination pairs in ONE set of colour
   // launches): the cell is evaluated for every source in turn, the weighted results are summed in registers and scattered once
+  int interleave;             // cell -> half-wave assignment (see the kernel)
   int nsrc;                   // 0 / 1: the single source u, p with the weights above
   const double *us[4], *ps[4];
   double fKu[4][4], fKp[4][4], fM[4][4]; // [destination pair][source]
@@ -125,7 +126,11 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   // after the other by the same lanes instead of at the same time by neighbouring ones (their atomics
   // on the shared nodes would serialise in L2)
   const long long nhalf = (long long)gridDim.x * 8, run = (ncells + nhalf - 1) / nhalf;
-  const long long first = ((long long)blockIdx.x * 8 + slot) * run;
+  // STRIDE = 1: every half-wave walks its own contiguous run of cells; STRIDE = 8: the eight half-waves of the workgroup take eight
+  // consecutive cells of the workgroup's run at a time (their rows are 32 bytes apart: denser sectors per gather / scatter instruction)
+  const long long wg_first = (long long)blockIdx.x * 8 * run, wg_end = wg_first + 8 * run;
+  const int STRIDE = prm.interleave ? 8 : 1;
+  const long long first = prm.interleave ? wg_first + slot : ((long long)blockIdx.x * 8 + slot) * run;
   // the DoFs of a cell are fetched while the previous cell is being computed
   struct CellIds {
     int cx, cy, cz;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   };
   auto ids = [&](long long cell) {
     CellIds q;
-    q.ok = cell < ncells && cell < first + run;
+    q.ok = cell < ncells && (prm.interleave ? cell < wg_end : cell < first + run);
     const long long cc = q.ok ? cell : 0;
     q.cx = 2 * int(cc % ncxc) + px; q.cy = 2 * int((cc / ncxc) % ncyc) + py; q.cz = 2 * int(cc / ((long long)ncxc * ncyc)) + pz;
     const int ix = 2 * q.cx + a, iy = 2 * q.cy + b, iz = 2 * q.cz + c;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = un[comp];
     }
     if (pnode) X[81 + a + 2 * b + 4 * c] = pn;
-    nxt = ids(first + (it2 + 1) / nsrc);
+    nxt = ids(first + STRIDE * ((it2 + 1) / nsrc));
     fetch(nxt, int((it2 + 1) % nsrc));
     wave_fence();
 
@@ -494,6 +499,8 @@ int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double
   b.dmask = c->dmask;
   b.nu = c->nu;
   b.cart = mesh->vertices ? 0 : 1;
+  b.interleave = 1;
+  if (const char *e = getenv("STFEM_STOKES_INTERLEAVE")) b.interleave = atoi(e) != 0;
   b.detJ = 1.0;
   for (int d = 0; d < 3; ++d) {
     const double h = (mesh->upper[d] - mesh->lower[d]) / c->nc[d];
