@@ -570,14 +570,19 @@ static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
                         ((c->nc[2] - (colour >> 2) + 1) / 2);
     if (n == 0) continue;
     prm.colour = colour;
-    // the workgroups walk over the cells; four times as many as are resident at once (two per CU) measured best:
-    // 1.00 against 1.35 ms for the cG(2) system on 64^3 cells, no difference for cG(1)
-    const unsigned grid = (unsigned)std::min<long long>((n + 7) / 8, (long long)c->n_cu * 8);
-    if (prm.nsrc > 1) {
-      if (prm.cart) hipLaunchKernelGGL((stokes_cell_kernel<true, true>), dim3(grid), dim3(256), 0, st, prm);
-      else hipLaunchKernelGGL((stokes_cell_kernel<false, true>), dim3(grid), dim3(256), 0, st, prm);
-    } else if (prm.cart) hipLaunchKernelGGL((stokes_cell_kernel<true, false>), dim3(grid), dim3(256), 0, st, prm);
-    else hipLaunchKernelGGL((stokes_cell_kernel<false, false>), dim3(grid), dim3(256), 0, st, prm);
+    // persistent workgroups: exactly as many as stay resident (measured on 64^3 cells, cG(1): 2 per CU 0.41 ms, 3: 0.50, 4: 0.43,
+    // 8: 0.45, one workgroup per 8 cells: 0.52 - long runs keep the prefetch of the next cell's DoFs going and leave no partial round)
+    static const int grid_env = [] {
+      const char *e = getenv("STFEM_STOKES_GRID"); // workgroups per CU of a colour launch (experiments)
+      return e ? std::max(1, atoi(e)) : 0;
+    }();
+    const void *kern = prm.nsrc > 1 ? (prm.cart ? (const void *)stokes_cell_kernel<true, true> : (const void *)stokes_cell_kernel<false, true>)
+                                    : (prm.cart ? (const void *)stokes_cell_kernel<true, false> : (const void *)stokes_cell_kernel<false, false>);
+    int resident = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, 256, 0) != hipSuccess || resident < 1) resident = 2;
+    const unsigned grid = (unsigned)std::min<long long>((n + 7) / 8, (long long)c->n_cu * (grid_env ? grid_env : resident));
+    void *args[] = {(void *)&prm};
+    (void)hipLaunchKernel(kern, dim3(grid), dim3(256), args, 0, st);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
