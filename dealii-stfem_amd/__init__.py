@@ -98,6 +98,7 @@ SIGNATURES = {
     "stfem_integrate_rhs_product": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, _vp, C.c_int, _vp]),
     "stfem_integrate_difference_product": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _dp, _vp]),
     "stfem_vector_axpby": (C.c_int, [_vp, C.c_double, _vp, C.c_double, _vp, _vp]),
+    "stfem_vector_set_zero": (C.c_int, [_vp, _vp, _vp]),
     "stfem_driver_last_error": (C.c_char_p, []),
     "stfem_gauss_rule": (C.c_int, [C.c_int, _dp, _dp]),
     "stfem_fe_time_points": (C.c_int, [C.c_int, C.c_int, _dp]),

@@ -107,6 +107,18 @@ struct stfem_comm {
     }                                                                                     \
   } while (0)
 
+// inside ncclGroupStart / GroupEnd: a failed call still closes the group (an open group would swallow every later
+// RCCL call of this thread) before the error is returned
+#define COMM_NCCL_IN_GROUP(call)                                                          \
+  do {                                                                                    \
+    ncclResult_t r_ = (call);                                                             \
+    if (r_ != ncclSuccess) {                                                              \
+      snprintf(g_comm_err, sizeof(g_comm_err), "%s: %s", #call, rccl().GetErrorString(r_)); \
+      (void)rccl().GroupEnd();                                                            \
+      return STFEM_ERR_COMM;                                                              \
+    }                                                                                     \
+  } while (0)
+
 extern "C" {
 
 const char *stfem_comm_last_error(void) { return g_comm_err; }
@@ -116,7 +128,8 @@ int stfem_comm_get_unique_id(void *id)
   if (!id) return STFEM_ERR_INVALID_ARGUMENT;
   static_assert(STFEM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
   if (!rccl().ok) {
-    snprintf(g_comm_err, sizeof(g_comm_err), "librccl.so not found: %s", dlerror() ? dlerror() : "");
+    const char *why = dlerror(); // (a second call returns NULL)
+    snprintf(g_comm_err, sizeof(g_comm_err), "librccl.so not found: %s", why ? why : "");
     return STFEM_ERR_UNSUPPORTED;
   }
   ncclUniqueId u;
@@ -211,8 +224,8 @@ int stfem_halo_begin(stfem_ctx *ctx, stfem_comm *c, stfem_vec *v, int lower, int
   int nz;
   int rc = plane_geometry(ctx, v, pb, nz);
   if (rc != STFEM_OK) return rc;
-  c->lower = lower; c->upper = upper; c->plane_bytes = pb;
   if (lower < 0 && upper < 0) {
+    c->lower = lower; c->upper = upper; c->plane_bytes = pb;
     c->pending = true;
     return STFEM_OK;
   }
@@ -229,15 +242,16 @@ int stfem_halo_begin(stfem_ctx *ctx, stfem_comm *c, stfem_vec *v, int lower, int
   const size_t count = pb / (stfem_ctx_precision(ctx) ? sizeof(float) : sizeof(double));
   COMM_NCCL(rccl().GroupStart());
   if (upper >= 0) {
-    COMM_NCCL(rccl().Send(ts, count, dt, upper, c->comm, c->stream));
-    COMM_NCCL(rccl().Recv(tr, count, dt, upper, c->comm, c->stream));
+    COMM_NCCL_IN_GROUP(rccl().Send(ts, count, dt, upper, c->comm, c->stream));
+    COMM_NCCL_IN_GROUP(rccl().Recv(tr, count, dt, upper, c->comm, c->stream));
   }
   if (lower >= 0) {
-    COMM_NCCL(rccl().Send(bs, count, dt, lower, c->comm, c->stream));
-    COMM_NCCL(rccl().Recv(br, count, dt, lower, c->comm, c->stream));
+    COMM_NCCL_IN_GROUP(rccl().Send(bs, count, dt, lower, c->comm, c->stream));
+    COMM_NCCL_IN_GROUP(rccl().Recv(br, count, dt, lower, c->comm, c->stream));
   }
   COMM_NCCL(rccl().GroupEnd());
   COMM_HIP(hipEventRecord(c->arrived, c->stream));
+  c->lower = lower; c->upper = upper; c->plane_bytes = pb; // (only a successful begin leaves an exchange pending)
   c->pending = true;
   return STFEM_OK;
 }
@@ -283,8 +297,8 @@ int stfem_ghost_update(stfem_ctx *ctx, stfem_comm *c, stfem_vec *v, int lower, i
   const ncclDataType_t dt = stfem_ctx_precision(ctx) ? ncclFloat : ncclDouble;
   const size_t count = pb / (stfem_ctx_precision(ctx) ? sizeof(float) : sizeof(double));
   COMM_NCCL(rccl().GroupStart());
-  if (lower >= 0) COMM_NCCL(rccl().Send(bs, count, dt, lower, c->comm, c->stream));
-  if (upper >= 0) COMM_NCCL(rccl().Recv(tr, count, dt, upper, c->comm, c->stream));
+  if (lower >= 0) COMM_NCCL_IN_GROUP(rccl().Send(bs, count, dt, lower, c->comm, c->stream));
+  if (upper >= 0) COMM_NCCL_IN_GROUP(rccl().Recv(tr, count, dt, upper, c->comm, c->stream));
   COMM_NCCL(rccl().GroupEnd());
   COMM_HIP(hipEventRecord(c->arrived, c->stream));
   COMM_HIP(hipStreamWaitEvent(st, c->arrived, 0));

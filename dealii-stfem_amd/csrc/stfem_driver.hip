@@ -239,11 +239,27 @@ __global__ __launch_bounds__(256) void integrate_difference_kernel(const CellGeo
   if (threadIdx.x == 0) { out[cell * 3] = red[0]; out[cell * 3 + 1] = red[256]; out[cell * 3 + 2] = red[512]; }
 }
 
+// y = a x + b y on up to eight blocks per launch (blockIdx.y = block).  A zero factor means "not read": a = 0 never
+// touches x, b = 0 never touches y's old content (0 * NaN and 0 * Inf would survive otherwise, where deal.II's
+// `dst = 0.` / equ() assign); x and y may be the same vector (no __restrict__).
+struct AxpbyBlocks {
+  const void *x[8];
+  void *y[8];
+};
 template <typename T>
-__global__ __launch_bounds__(256) void axpby_kernel(int64_t n, T a, const T *__restrict__ x, T b, T *__restrict__ y)
+__global__ __launch_bounds__(256) void axpby_kernel(int64_t n, T a, T b, const AxpbyBlocks blocks)
 {
-  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    y[i] = b == T(0) ? a * x[i] : a * x[i] + b * y[i];
+  const T *x = static_cast<const T *>(blocks.x[blockIdx.y]);
+  T *y = static_cast<T *>(blocks.y[blockIdx.y]);
+  const int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+  if (a == T(0) && b == T(0))
+    for (int64_t i = i0; i < n; i += stride) y[i] = T(0);
+  else if (a == T(0))
+    for (int64_t i = i0; i < n; i += stride) y[i] = b * y[i];
+  else if (b == T(0))
+    for (int64_t i = i0; i < n; i += stride) y[i] = a * x[i];
+  else
+    for (int64_t i = i0; i < n; i += stride) y[i] = a * x[i] + b * y[i];
 }
 
 // device copies of the geometry and of the tables of QGauss(nq) against the context's nodal basis
@@ -453,15 +469,27 @@ int stfem_vector_axpby(stfem_ctx *c, double a, const stfem_vec *x, double b, stf
   DRV_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 4096);
-  for (int blk = 0; blk < x->nb; ++blk) {
-    if (c->prec)
-      hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid), dim3(256), 0, st, c->ndofs, float(a), static_cast<const float *>(x->blk[blk]),
-                         float(b), static_cast<float *>(y->blk[blk]));
-    else
-      hipLaunchKernelGGL(axpby_kernel<double>, dim3(grid), dim3(256), 0, st, c->ndofs, a, static_cast<const double *>(x->blk[blk]), b,
-                         static_cast<double *>(y->blk[blk]));
+  (void)hipGetLastError();
+  for (int b0 = 0; b0 < x->nb; b0 += 8) {
+    const int nb = std::min(8, x->nb - b0);
+    AxpbyBlocks bl{};
+    for (int j = 0; j < nb; ++j) {
+      bl.x[j] = x->blk[b0 + j];
+      bl.y[j] = y->blk[b0 + j];
+    }
+    if (c->prec) hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid, nb), dim3(256), 0, st, c->ndofs, float(a), float(b), bl);
+    else hipLaunchKernelGGL(axpby_kernel<double>, dim3(grid, nb), dim3(256), 0, st, c->ndofs, a, b, bl);
   }
   return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+
+int stfem_vector_set_zero(stfem_ctx *c, stfem_vec *y, void *stream)
+{
+  if (!c || !y || y->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  DRV_TRY(hipSetDevice(c->device));
+  const size_t bytes = size_t(c->ndofs) * (c->prec ? sizeof(float) : sizeof(double));
+  for (int j = 0; j < y->nb; ++j) DRV_TRY(hipMemsetAsync(y->blk[j], 0, bytes, static_cast<hipStream_t>(stream)));
+  return STFEM_OK;
 }
 
 } // extern "C"

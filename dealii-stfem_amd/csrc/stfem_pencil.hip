@@ -619,13 +619,18 @@ template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, c
   else if (coef) STFEM_LAUNCH(false, true);
   else STFEM_LAUNCH(false, false);
 #undef STFEM_LAUNCH
-  if (hipGetLastError() != hipSuccess) return -3;
-  // (the tile counters are zero on entry: zeroed at allocation and again after every sweep)
-  if (pp.ntyw > 1 || pp.ntc > 1) {
+  // The tile counters are zero on entry: zeroed at allocation and again after every sweep - by the fix-up kernel, or
+  // by a memset where there is no fix-up or a launch has failed (counters left at their end values would make every
+  // later sweep on this context pull no tile and return with dst unwritten).
+  const bool sweep_ok = hipGetLastError() == hipSuccess;
+  bool fixed_up = false;
+  if (sweep_ok && (pp.ntyw > 1 || pp.ntc > 1)) {
     hipLaunchKernelGGL((st_pencil_fixup<P>), dim3(nblocks, prm.nbo, 2), dim3(256), 0, st, prm, pp, NBM, PG::CPW, TY);
-    if (hipGetLastError() != hipSuccess) return -3;
-  } else if (hipMemsetAsync(pp.work, 0, 8 * 32 * sizeof(int), st) != hipSuccess)
-    return -3;
+    fixed_up = hipGetLastError() == hipSuccess;
+    if (!fixed_up) (void)hipMemsetAsync(pp.work, 0, 8 * 32 * sizeof(int), st);
+    return fixed_up ? 0 : -3;
+  }
+  if (hipMemsetAsync(pp.work, 0, 8 * 32 * sizeof(int), st) != hipSuccess || !sweep_ok) return -3;
   return 0;
 }
 

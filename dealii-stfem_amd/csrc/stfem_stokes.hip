@@ -16,8 +16,7 @@
 // Thread layout: one wave owns two cells (32 lanes each, 27 = 3^3 active).  Evaluation and
 // integration are sum-factorised (three 1D stages each, see stokes_cell_kernel); the MappingQ1
 // Jacobian is evaluated on the fly from the eight cell vertices (24 doubles per cell instead of a
-// stored metric), or is a constant diagonal on axis-aligned boxes.  The scatter still uses fp64
-// atomics into zeroed destinations.
+// stored metric), or is a constant diagonal on axis-aligned boxes.
 #include "../../include/stfem.h"
 #include "host_tables.h"
 
@@ -578,8 +577,10 @@ static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
     }();
     const void *kern = prm.nsrc > 1 ? (prm.cart ? (const void *)stokes_cell_kernel<true, true> : (const void *)stokes_cell_kernel<false, true>)
                                     : (prm.cart ? (const void *)stokes_cell_kernel<true, false> : (const void *)stokes_cell_kernel<false, false>);
-    int resident = 2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, 256, 0) != hipSuccess || resident < 1) resident = 2;
+    // resident workgroups per CU of the four instantiations, asked once (not on the launch path)
+    static int resident_of[4] = {0, 0, 0, 0};
+    int &resident = resident_of[(prm.nsrc > 1 ? 2 : 0) + (prm.cart ? 1 : 0)];
+    if (resident < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, 256, 0) != hipSuccess || resident < 1)) resident = 2;
     const unsigned grid = (unsigned)std::min<long long>((n + 7) / 8, (long long)c->n_cu * (grid_env ? grid_env : resident));
     void *args[] = {(void *)&prm};
     (void)hipLaunchKernel(kern, dim3(grid), dim3(256), args, 0, st);

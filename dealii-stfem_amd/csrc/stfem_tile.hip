@@ -43,24 +43,12 @@ constexpr int tile_cells_per_wave(int p, int nbm)
   const int cpw = (64 / (p + 1)) / nbm;
   return p * cpw + 1 > 64 ? 63 / p : cpw;
 }
-// Tile rows of two wave-widths.  Every wave handles SX = 2 cell groups one after the other on the
-// fp64 Cartesian path: rows of 49 instead of 25 doubles for Q4 x 2 blocks, -20 % HBM fetch, half
-// the 32-byte partial writes, 7 % less time on cfg 1 (A/B on one box: 0.473 -> 0.440 ms).  Not
-// on the general path (metric-bound anyway; with SX = 2 its fp64 instantiation spills, and a spilled
-// destination of the asm-issued src prefetch is stored before its data has landed: that was the
-// parity failure of round 1, see load_plane_async) and not in fp32 (128-VGPR budget).  (Two waves
-// side by side in an 8-wave workgroup, one per CU, measured slower in round 1: its compute and memory
-// phases no longer overlap with a second workgroup's.)
+// Cell groups a wave handles one after the other (rows of two wave-widths).  Round 1 ran the fp64 Cartesian
+// kernels with SX = 2 (7 % faster on cfg 1); since round 3 the carried plane and the x-slab values have LDS
+// regions of their own (fixed summation order, see the kernel), with which an SX = 2 slab no longer fits twice
+// into a CU - and the Cartesian systems are served by the pencil sweep (stfem_pencil.hip) anyway.
 constexpr int tile_wx(int, int) { return 1; }
-constexpr int tile_sx(int p, int nbm, bool general)
-{
-#ifdef STFEM_F32
-  (void)p; (void)nbm; (void)general;
-  return 1;
-#else
-  return (!general && nbm <= 3 && p * 2 * tile_cells_per_wave(p, nbm) + 1 <= 64) ? 2 : 1; // more blocks spill
-#endif
-}
+constexpr int tile_sx(int, int, bool) { return 1; }
 
 constexpr int tile_threads(int p, int nbm) { return 256 * tile_wx(p, nbm); }
 constexpr int tile_min_blocks(int p, int nbm, int minw) { return minw / tile_wx(p, nbm) > 0 ? minw / tile_wx(p, nbm) : 1; }
@@ -85,9 +73,10 @@ template <int P, int NBM, bool GEN> struct TileGeom {
   static constexpr int LDS_PER_WAVE = CWW * NBM * G::CBS;  // transpose slab of one wave
   static constexpr int TRANS = NWAVES * LDS_PER_WAVE;      // transpose slabs
   static constexpr int MAIN = ACC > TRANS ? ACC : TRANS;
-  static constexpr int CARRY = NBM * PLANE;                // top plane carried between layers
-  static constexpr int CARRY_REGS = (CARRY + NT - 1) / NT; // ... in registers, CARRY_REGS per thread
-  static constexpr int LDS_DOUBLES = MAIN;
+  static constexpr int CARRY = NBM * PLANE;                // top plane carried between layers: its own LDS region
+  static constexpr int CARRY_REGS = (CARRY + NT - 1) / NT; // copy passes per thread
+  static constexpr int XSL = 2 * NBM * N * TY;             // x-slab values of the layer (both sides): their own region
+  static constexpr int LDS_DOUBLES = MAIN + CARRY + XSL;
 };
 
 struct TileCoords {
@@ -215,6 +204,11 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
   constexpr int TX = TG::TX, TY = TG::TY, PLANE = TG::PLANE;
   __shared__ real_t smem[TG::LDS_DOUBLES];
   real_t *acc = smem; // [blk][k][Y][X], aliases the transpose slabs
+  // Every DoF of the slab is summed in a FIXED order (bitwise reproducible results): its owner lane stores
+  // own + carried plane + x-slab value, then the x-neighbour cell (same wave: LDS operations of a wave execute
+  // in order) adds, and after the next barrier the cells of the wave below add theirs (one wave, program order).
+  real_t *cr = smem + TG::MAIN;       // [blk][Y][X]: top plane of the previous layer
+  real_t *xr = cr + TG::CARRY;        // [side][blk][k][Y]: partial sums of the odd x-neighbours' shared columns
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -289,11 +283,6 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
   const int64_t tile_goff = int64_t(P) * t.cx0 + int64_t(prm.nx) * (int64_t(P) * t.cy0) +
                             plane_stride * (int64_t(P) * t.cz0);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-  // top plane of the previous layer: element tid + NT*m of [blk][Y][X] lives in this thread
-  real_t carry[TG::CARRY_REGS];
-  STFEM_UNROLL
-  for (int m = 0; m < TG::CARRY_REGS; ++m) carry[m] = real_t(0);
 
   real_t PA[SX][N * N];
   STFEM_UNROLL
@@ -416,6 +405,11 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     // from draining the src prefetch (issued below) when their registers are recycled later
     STFEM_UNROLL
     for (int m = 0; m < XE; ++m) asm volatile("" : "+v"(xe[m]));
+    if (collect_left || collect_right) { // (zeros where nothing is collected; read by the owner lanes after the barrier)
+      STFEM_UNROLL
+      for (int m = 0; m < XE; ++m)
+        if (tid + NT * m < 2 * nrows) xr[tid + NT * m] = xe[m];
+    }
 
     if (masked) {
       STFEM_UNROLL
@@ -431,51 +425,49 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
     STFEM_LAYER_BARRIER(); // all waves are done with the transpose slabs: the region becomes `acc`
     STFEM_TL(3);
 
-    // owner lanes initialise their DoFs
+    // owner lanes initialise their DoFs: own value + plane carried from the previous layer + x-slab value
     STFEM_UNROLL
     for (int h = 0; h < SX; ++h)
       if (out_active[h] && !(ex & 4)) {
         real_t *a = acc + a_off[h];
+        const real_t *c0 = cr + blk * PLANE + (P * cyl) * TX + P * cxl[h];
+        const real_t *x0 = xr + (blk * N + k) * TY + P * cyl;
+        const bool use_c = layer > 0 && k == 0;
+        const bool use_l = collect_left && cxl[h] == 0, use_r = collect_right && own_x_hi[h];
         STFEM_UNROLL
         for (int y = 0; y < N; ++y)
           STFEM_UNROLL
         for (int x = 0; x < N; ++x) {
           const bool owned = (x < P || own_x_hi[h]) && (y < P || own_y_hi);
-          if (owned) a[y * TX + x] = PA[h][y * N + x];
+          if (!owned) continue;
+          real_t v = PA[h][y * N + x];
+          if (use_c) v += c0[y * TX + x];
+          if (x == 0 && use_l) v += x0[y];
+          if (x == P && use_r) v += x0[nrows + y];
+          a[y * TX + x] = v;
         }
+      }
+    // ... the x = P column of a cell is the x = 0 column of the next cell of the row, which this same wave owns
+    STFEM_UNROLL
+    for (int h = 0; h < SX; ++h)
+      if (out_active[h] && !(ex & 4) && !own_x_hi[h]) {
+        real_t *a = acc + a_off[h];
+        STFEM_UNROLL
+        for (int y = 0; y < N; ++y)
+          if (y < P || own_y_hi) atomicAdd(&a[y * TX + P], PA[h][y * N + P]);
       }
     STFEM_TL(4);
     __syncthreads();
     STFEM_TL(5);
-    // the other sharers of a face / edge / vertex DoF add their part (ds_add_f64) ...
-    STFEM_UNROLL
-    for (int h = 0; h < SX; ++h)
-      if (out_active[h] && !(ex & 4)) {
-        real_t *a = acc + a_off[h];
-        STFEM_UNROLL
-        for (int y = 0; y < N; ++y)
+    // ... and the y = P row that of the cells above, owned by the next wave
+    if (!own_y_hi) {
+      STFEM_UNROLL
+      for (int h = 0; h < SX; ++h)
+        if (out_active[h] && !(ex & 4)) {
+          real_t *a = acc + a_off[h];
           STFEM_UNROLL
-        for (int x = 0; x < N; ++x) {
-          if (x < P && y < P) continue;
-          const bool owned = (x < P || own_x_hi[h]) && (y < P || own_y_hi);
-          if (!owned) atomicAdd(&a[y * TX + x], PA[h][y * N + x]);
+          for (int x = 0; x < N; ++x) atomicAdd(&a[P * TX + x], PA[h][P * N + x]);
         }
-      }
-    // ... as do the plane carried over from the previous layer and the x-slab values
-    if (layer > 0) {
-      STFEM_UNROLL
-      for (int m = 0; m < TG::CARRY_REGS; ++m) {
-        const int e = tid + NT * m, j = e / PLANE;
-        if (e < prm.nbo * PLANE) atomicAdd(&acc[j * (N - 1) * PLANE + e], carry[m]);
-      }
-    }
-    if (collect_left || collect_right) {
-      STFEM_UNROLL
-      for (int m = 0; m < XE; ++m) {
-        int side, j, kk, Y;
-        const int idx = xe_slot(m, side, j, kk, Y);
-        if (idx >= 0) atomicAdd(&acc[idx], xe[m]);
-      }
     }
     // the result planes are in LDS now: fetch the next layer's src planes (in flight during the
     // store phase; a separate prefetch buffer one layer ahead would need > 256 VGPRs)
@@ -628,7 +620,7 @@ void st_sweep_cart_tile(const SweepParams prm, const TilePlan tp)
       STFEM_UNROLL
       for (int m = 0; m < TG::CARRY_REGS; ++m) {
         const int e = tid + NT * m, j = e / PLANE;
-        if (e < prm.nbo * PLANE) carry[m] = acc[(j * (N - 1) + P) * PLANE + e];
+        if (e < prm.nbo * PLANE) cr[e] = acc[(j * (N - 1) + P) * PLANE + e];
       }
     }
     STFEM_TL(9);

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
     s_src[r] = os;
     if (r >= row0 && r < row0 + MPAD) s_dst[r - row0] = od;
   }
+  // padded row tiles of the last part may lie beyond the table (parts * MPAD > VK_MAX_ROWS): no rows there
+  for (int r = threadIdx.x; r < MPAD; r += 256)
+    if (row0 + r >= VK_MAX_ROWS) s_dst[r] = VK_NO_ROW;
   // the inverse of this class, [kpad][mpad] with mpad = all row tiles; this workgroup's MPAD columns of every k row
   const T *Binv = static_cast<const T *>(prm.blocks) + size_t(cls) * prm.kpad * prm.mpad + row0;
   const int base = prm.cell[(quad * 4 + wave) * 16 + (lane & 15)]; // this lane's cell (column of X and Y)
@@ -736,8 +739,10 @@ static int vanka_create_per_cell_device(stfem_vanka *v, const double *Alpha, con
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
   const double need = double(c->ncells) * double(bsz) * double(c->es);
-  const double budget = 6e9; // scratch of one batch
-  if (need + 3.0 * double(km_layer) + double(b_layer) > 0.9 * double(free_b)) {
+  // scratch of one batch of L cell layers: (L + 2) layers of cell matrices + L layers of fp64 blocks; at most 6 GB,
+  // and never more than what is left beside the blocks themselves
+  const double budget = std::min(6e9, 0.9 * double(free_b) - need);
+  if (budget < 3.0 * double(km_layer) + double(b_layer)) {
     snprintf(g_vanka_err, sizeof(g_vanka_err), "per-cell blocks of %lld cells need %.1f GB (%.1f GB free)", (long long)c->ncells, need * 1e-9, double(free_b) * 1e-9);
     return STFEM_ERR_OUT_OF_MEMORY;
   }

@@ -211,7 +211,7 @@ public:
   void interpolate(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
     if (dst.n_blocks() > src.n_blocks()) throw std::invalid_argument("Interpolation only from fine to coarse");
-    axpby(0.0, dst, 0.0, dst, stream);
+    set_zero(dst, stream);
     transfer_and_add(dst, blk_index_lo, interpolate_down_matrix, src, blk_index_hi, stream);
   }
   const FullMatrix<Number> &prolongation() const { return prolongation_matrix; }
@@ -267,7 +267,7 @@ public:
   {}
   void prolongate(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
   {
-    axpby(0.0, dst, 0.0, dst, stream);
+    set_zero(dst, stream);
     prolongate_and_add(to_level, dst, src, stream);
   }
   void prolongate_and_add(unsigned to_level, BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
@@ -293,7 +293,7 @@ public:
   // the zeroing of the coarser level vectors (initialize_dof_vector without omit_zeroing_entries, stmg.h:408-412)
   void zero_coarser(std::vector<BlockVectorType> &dst, void *stream = nullptr) const
   {
-    for (size_t l = 0; l + 1 < dst.size(); ++l) axpby(0.0, dst[l], 0.0, dst[l], stream);
+    for (size_t l = 0; l + 1 < dst.size(); ++l) set_zero(dst[l], stream);
   }
   unsigned n_levels() const { return unsigned(blk_indices.size()); }
   const BlockSlice &blk(unsigned l) const { return blk_indices[l]; }
@@ -371,7 +371,7 @@ public:
     P.vmult(dst, src, stream);
     axpby(0.0, dst, 1.0 / theta, dst, stream); // x_1
     if (degree < 2) return;
-    axpby(0.0, old, 0.0, old, stream);          // x_0 = 0
+    set_zero(old, stream);                      // x_0 = 0
     const double sigma = theta / delta;
     double rho = 1.0 / sigma;
     for (unsigned k = 1; k < degree; ++k) {
@@ -552,7 +552,7 @@ private:
   // their own dependent-load chains, the launches already overlap them.
   template <typename Number2> void cycle(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const
   {
-    if (!stream_ && use_graph) check(stfem_stream_create(&stream_), "stfem_stream_create");
+    if (!stream_ && use_graph) check(stfem_stream_create(&stream_.s), "stfem_stream_create");
     transfer_block->copy_to_mg(defect, src, stream_);
     const unsigned n_levels = transfer_block->n_levels();
     if (solution.size() != n_levels) {
@@ -600,7 +600,21 @@ private:
   std::unique_ptr<STMGTransferBlockMatrixFree<Number>> transfer_block;
   std::vector<PreconditionSTMG<Number, LevelMatrixType>> mg_smoother;
   mutable std::vector<BlockVectorType> defect, solution, t, d_;
-  mutable void *stream_ = nullptr; // (not destroyed: the object lives as long as the solver)
+  // the cycle's own stream (created on the first graph capture); the holder destroys it with the object,
+  // after the graph (members are destroyed in reverse order of declaration)
+  struct StreamHolder {
+    void *s = nullptr;
+    StreamHolder() = default;
+    StreamHolder(const StreamHolder &) = delete;
+    StreamHolder &operator=(const StreamHolder &) = delete;
+    ~StreamHolder()
+    {
+      if (s) stfem_stream_destroy(s);
+    }
+    operator void *() const { return s; }
+    bool operator!() const { return s == nullptr; }
+  };
+  mutable StreamHolder stream_;
   mutable std::shared_ptr<stfem_graph> graph_;
   mutable unsigned cycles_run = 0;
   bool use_graph = [] {

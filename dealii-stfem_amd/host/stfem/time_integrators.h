@@ -20,6 +20,11 @@ template <typename Number> void axpby(double a, const BlockVectorT<Number> &x, d
 {
   check(stfem_vector_axpby(x.context()->h, a, x.handle(), b, y.handle(), stream), "stfem_vector_axpby");
 }
+// `v = 0.` (a memset: whatever v held, NaN included, is gone)
+template <typename Number> void set_zero(BlockVectorT<Number> &v, void *stream = nullptr)
+{
+  check(stfem_vector_set_zero(v.context()->h, v.handle(), stream), "stfem_vector_set_zero");
+}
 template <typename Number> double norm(const BlockVectorT<Number> &x) { return std::sqrt(dot(x, x)); }
 
 // One block of a block vector as a one-block vector of its own (a view: nothing is copied)
@@ -348,7 +353,7 @@ public:
     const auto t1 = std::chrono::steady_clock::now();
     this->solver.solve(this->matrix, u, rhs, this->preconditioner);
     const unsigned nt_dofs = AixB.m();
-    axpby(0.0, v, 0.0, v);
+    set_zero(v);
     for (unsigned it = 0; it < this->n_timesteps_at_once; ++it) {
       const V pu = it == 0 ? block_view(prev_u, 0) : block_view(u, it * nt_dofs - 1);
       tensorproduct_add(v, AixB, u, it * nt_dofs);
@@ -394,7 +399,7 @@ public:
         const double t = time + time_step * it + tq[q] * time_step;
         const std::vector<double> L = lagrange_values(nodes, tq[q]);
         // evaluate_numerical_solution: DG: sum_i L_i x_i; CGP: L_0 prev + sum_{i>=1} L_i x_{i-1}
-        axpby(0.0, numeric, 0.0, numeric);
+        set_zero(numeric);
         if (type == TimeStepType::DG) {
           for (unsigned i = 0; i < nt_dofs; ++i) axpby(L[i], block_view(x, it * nt_dofs + i), 1.0, numeric);
         } else {

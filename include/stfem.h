@@ -14,7 +14,11 @@
  * success or a negative stfem_status; nothing throws across the boundary.
  * "device pointer" = HIP device memory of the context's device.  `stream` is a
  * hipStream_t passed as void* (NULL = the null stream).  Calls are
- * asynchronous on `stream` unless noted.  One host thread per context.
+ * asynchronous on `stream` unless noted.  One host thread per context, and ONE
+ * STREAM AT A TIME per context: a context owns device workspace (the sweeps'
+ * halo slabs and tile counters, the transfers' temporaries) that two operations
+ * of the same context running concurrently on different streams would share.
+ * Work on different contexts may overlap freely.
  *
  * DoF numbering: lexicographic over the structured mesh,
  * index = ix + nx*(iy + ny*iz), nx = p*ncell[0]+1, x fastest.
@@ -291,7 +295,9 @@ const char *stfem_vanka_last_error(void);
  * integrate_difference: out = { sum JxW (u_h - u)^2, max |u_h - u|, sum JxW |grad u_h - grad u|^2 } over the
  *                    quadrature points (VectorTools::integrate_difference for L2_norm squared, Linfty_norm,
  *                    H1_seminorm squared); exact_grad_at_points [cell][q][3] may be NULL (third entry 0).  Synchronous.
- * vector_axpby:      y = a x + b y on every block (b = 0: y is overwritten, never read) */
+ * vector_axpby:      y = a x + b y on every block.  A zero factor means "not read": b = 0 overwrites y (equ), a = 0 never
+ *                    touches x (a = b = 0 assigns zero whatever y held, NaN included); x and y may be the same vector
+ * vector_set_zero:   y = 0 (`dst = 0.0` of the reference's smoother, include/stmg.h:837) */
 int stfem_support_points(const stfem_ctx *ctx, double *out);
 int stfem_quadrature_points(const stfem_ctx *ctx, int nq, double *out);
 int stfem_integrate_rhs(stfem_ctx *ctx, int nq, const double *f_at_points, stfem_vec *dst, int block, void *stream);
@@ -303,6 +309,7 @@ int stfem_integrate_rhs_product(stfem_ctx *ctx, int nq, double amplitude, double
 int stfem_integrate_difference_product(stfem_ctx *ctx, int nq, const stfem_vec *u, int block, double amplitude, double frequency, double out[3],
                                        void *stream);
 int stfem_vector_axpby(stfem_ctx *ctx, double a, const stfem_vec *x, double b, stfem_vec *y, void *stream);
+int stfem_vector_set_zero(stfem_ctx *ctx, stfem_vec *y, void *stream);
 const char *stfem_driver_last_error(void);
 /* QGauss(n) on [0, 1]; the support points of the temporal basis, get_time_quad (fe_time.cc:152-161): QGaussLobatto(r + 1)
  * for cG(r) (type 0), QGaussRadau(r + 1, right) for dG(r) (type 1); r + 1 values */

@@ -166,9 +166,7 @@ def test_vcycle_vs_oracle(ttype, k, n, nsteps, p, ctype, pmg, distort, number, t
             assert abs(omegas[l] - want) < (1e-8 if number == "double" else 2e-3) * want, (l, omegas[l], want)
     want = mg.vmult(src)
     assert rel(dst, want) < (1e-9 if number == "double" else 5e-3)
-    # the cycle recorded into a hipGraph and its replay give the result of the plain launches
-    recorded, replayed, size = (float(x) for x in res.stdout.split("graph: recorded")[1].replace("replayed", "").replace("of", "").split())
-    assert recorded <= 1e-14 * size and replayed <= 1e-14 * size, res.stdout
+    # (the hipGraph record / replay of the same cycle is checked in tests/test_zz_reproducibility.py, collected last)
 
 
 @pytest.mark.parametrize("number", ["double", "float"])
