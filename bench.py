@@ -7,11 +7,12 @@
 A "step" = one SystemMatrix::vmult (reference include/operators.h:536-559) of the all-at-once
 space-time system  dst = (Alpha (x) K + Beta (x) M) src  on synthetic data resident in HBM.
 N = 1: BASELINE.json configs[1] (72^3 cells, Q4, cG(2) -> 2 blocks, 48 275 138 space-time DoFs).
-N > 1: the configs[2] mesh type (vertices perturbed by 0.15 h -> general-geometry path), z-slabs,
-one packed interface-plane exchange per vmult over RCCL send/recv, no other collective on the data
-path.  Default "weak": every rank owns a 72 x 72 x 72-cell slab of a 72 x 72 x 72N mesh (N = 8 has
-exactly the cell and DoF count of configs[2]); --scaling strong: the fixed 144^3 configs[2] mesh
-cut into N slabs (run it at N = 1 too for a strong-scaling curve).  The JSON says which ran.
+N > 1: BASELINE configs[2] - the fixed 144^3-cell mesh with vertices perturbed by 0.15 h (general-geometry
+path, 383 M space-time DoFs) cut into N z-slabs: STRONG scaling, as north_star asks (>= 6x at 8 GPUs); one
+packed interface-plane exchange per vmult over RCCL send/recv, no other collective on the data path.  The
+line also carries the time of the SAME mesh on one GPU (rank 0 runs it after the timed region), because the
+default N = 1 line is configs[1] and not the one-GPU point of this curve.  --scaling weak: every rank owns a
+72 x 72 x 72-cell slab of a 72 x 72 x 72N mesh instead.  The JSON says which ran.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
 """
@@ -60,6 +61,23 @@ def cpu_baseline(stfem, degree, r, cells, threads):
                       f"across cells and OpenMP on {threads} cores; deal.II is unavailable, so not the reference binary"}
 
 
+SWEEP_SOURCES = ["stfem_pencil.hip", "stfem_tile.hip", "stfem_general.hip", "stfem_core.h", "stfem_device.h", "stfem_kernels.h",
+                 "stfem_kernels_decl.h", "stfem_capi.hip"]
+
+
+def sweep_source_hash():
+    """sha256 over the sources that decide what a vmult moves (kernels + planner): a committed PMC profile is only
+    reported as `roofline.traffic` while these are the files it was taken with (tools/summarize_pmc.py records it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SWEEP_SOURCES:
+        path = os.path.join(ROOT, "dealii-stfem_amd", "csrc", name)
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def measured_traffic(kernel_name, general):
     """HBM bytes per vmult from the committed rocprofv3 PMC passes of THIS command
     (profiles/latest/traffic.json for the Cartesian cfg-1 run, traffic_general.json for the perturbed
@@ -72,6 +90,8 @@ def measured_traffic(kernel_name, general):
             t = json.load(f)
         if not kernel_name.startswith(t.get("kernel", "?")) or "f32" in kernel_name:
             return None, None
+        if t.get("sources_sha256") != sweep_source_hash():
+            return None, os.path.relpath(path, ROOT) + " is STALE (kernel sources changed since the PMC passes): not reported"
         return 1024.0 * (2.0 * t["fetch_kb_per_vmult"] + t["write_kb_per_vmult"]), os.path.relpath(path, ROOT)
     except (OSError, KeyError, ValueError):
         return None, None
@@ -85,12 +105,14 @@ def main():
     ap.add_argument("--cells", type=int, default=72, help="cells per direction per GPU")
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--time-degree", type=int, default=2)
+    ap.add_argument("--timesteps-at-once", type=int, default=1,
+                    help="time steps per slab (the reference's n_timesteps_at_once, fe_time.h:373-402): cG(r) x s steps = r s blocks")
     ap.add_argument("--distort", type=float, default=None,
                     help="interior-vertex jitter in units of h (0.15 = BASELINE configs[2] mesh); 0 = Cartesian. "
                          "Default: 0 at --gpus 1 (configs[1]), 0.15 at --gpus N > 1 (the configs[2] mesh)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = 72^3 cells per GPU (N = 8 is exactly configs[2]); strong = the fixed "
-                         "--strong-cells^3 mesh (144 = configs[2]) cut into N z-slabs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1 default: strong = the fixed --strong-cells^3 mesh (144 = configs[2]) cut into N z-slabs; "
+                         "weak = 72^3 cells per GPU.  N = 1 default: the configs[1] mesh (reported as weak: its own point)")
     ap.add_argument("--strong-cells", type=int, default=144)
     ap.add_argument("--number", choices=["double", "float"], default="double",
                     help="operator Number type: double (headline) or float (the reference's multigrid-level precision)")
@@ -108,6 +130,8 @@ def main():
                     help="1: BASELINE configs[1] / [2] (heat, the contract line); 3: configs[3] = wave equation, Q3 x dG(2), "
                          "80^3 cells on [-1,1]^3 per GPU, Coefficient(1,9,16) per cell (extra line, not the contract metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-gpu-point", action="store_true",
+                    help="N > 1, strong scaling: do not run the whole mesh on rank 0's GPU after the timed region")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cells per direction of the CPU baseline mesh (0: as the GPU run)")
     args = ap.parse_args()
 
@@ -139,6 +163,8 @@ def main():
 
     if args.distort is None:
         args.distort = 0.0 if world == 1 else 0.15
+    if args.scaling is None:
+        args.scaling = "weak" if world == 1 else "strong"
     if args.config == 3:
         if world != 1:
             raise SystemExit("--config 3 is a one-GPU line")
@@ -153,7 +179,7 @@ def main():
     slab = dmod.make_slab(global_nc, rank, world)
     # tests/tp_01.cc:106-109 with 9 subdivisions, refinement 3: tau = 1/144
     tau = 1.0 / 144
-    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, r, tau, 1)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, r, tau, args.timesteps_at_once)
     nb = Alpha.shape[0]
     if args.distort:
         verts = stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, zext), args.distort, 5489,
@@ -241,13 +267,20 @@ def main():
             box = [raw]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        try:
-            comm = dmod.Communicator(rank, world, local_rank, bcast)
-        except Exception as e:  # noqa: BLE001  (reported below; every rank must take the same path)
-            print(f"[bench] rank {rank}: RCCL communicator behind the C-ABI not available ({e})", file=sys.stderr, flush=True)
-        ok = torch.tensor([1 if comm is not None else 0], device=xdev)
+        # agree that every rank can bind RCCL BEFORE any rank enters the collective construction (a rank that
+        # fails early would leave the others blocked in the broadcast / ncclCommInitRank)
+        ok = torch.tensor([1 if dmod.Communicator.available() else 0], device=xdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            try:
+                comm = dmod.Communicator(rank, world, local_rank, bcast)
+            except Exception as e:  # noqa: BLE001  (reported below; every rank must take the same path)
+                print(f"[bench] rank {rank}: RCCL communicator behind the C-ABI not available ({e})", file=sys.stderr, flush=True)
+            ok = torch.tensor([1 if comm is not None else 0], device=xdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
             comm, args.exchange = None, "torch"
     lo_rank, up_rank = dmod.neighbours(slab)
 
@@ -323,12 +356,43 @@ def main():
     kms = sum(a.elapsed_time(b) for a, b in kernel_ms) / len(kernel_ms)
     xms = sum(a.elapsed_time(b) for a, b in exchange_ms) / len(exchange_ms) if exchange_ms else 0.0
 
+    # strong scaling: the one-GPU point of THIS curve, measured here (the default N = 1 line is configs[1], another mesh).
+    # Rank 0 runs the whole mesh on its GPU after the timed region; the other ranks wait at the final barrier.
+    one_gpu_ms = None
+    if world > 1 and args.scaling == "strong" and rank == 0 and not args.no_one_gpu_point and args.backend == "nccl":
+        try:
+            del dst, src
+            del dst_t, src_t
+            torch.cuda.empty_cache()
+            if args.distort:
+                gctx = stfem.MatrixFreeOperator(p, global_nc, vertices=stfem.mesh_vertices(global_nc, (0, 0, 0), (1, 1, zext), args.distort, 5489),
+                                                number=args.number, device=local_rank)
+            else:
+                gctx = stfem.MatrixFreeOperator(p, global_nc, lower=(0, 0, 0), upper=(1, 1, zext), number=args.number, device=local_rank)
+            gA = stfem.SystemMatrix(gctx, Alpha, Beta)
+            gs = torch.rand((nb, gctx.n_dofs), dtype=tdt, device=dev, generator=gen) * 2 - 1
+            gd = torch.zeros((nb, gctx.n_dofs), dtype=tdt, device=dev)
+            gsrc = stfem.BlockVector(gctx, device_ptrs=[gs[b].data_ptr() for b in range(nb)])
+            gdst = stfem.BlockVector(gctx, device_ptrs=[gd[b].data_ptr() for b in range(nb)])
+            for _ in range(3):
+                gA.vmult(gdst, gsrc, stream=stream())
+            torch.cuda.synchronize()
+            reps = max(5, min(args.steps, 20))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                gA.vmult(gdst, gsrc, stream=stream())
+            torch.cuda.synchronize()
+            one_gpu_ms = 1e3 * (time.perf_counter() - t1) / reps
+            del gsrc, gdst, gs, gd, gA, gctx
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] one-GPU point of the strong-scaling curve not measured: {e}", file=sys.stderr, flush=True)
+
     if rank == 0:
         # 16 B per space-time DoF per vmult (8 B src read + 8 B dst write)
         alg_bytes = 2.0 * esz * nb * ndofs  # fp64: 16 B per DoF; fp32: 8 B
         achieved = alg_bytes / (kms * 1e-3) / 1e9
         traffic, traffic_file = (measured_traffic(ctx.last_kernel_name, bool(args.distort))
-                                 if (world, n, p, r, args.number) == (1, 72, 4, 2, "double") and args.distort in (0.0, 0.15)
+                                 if (world, n, p, r, args.number, args.timesteps_at_once) == (1, 72, 4, 2, "double", 1) and args.distort in (0.0, 0.15)
                                  else (None, None))
         out = {
             "metric": "space-time DoF/s per vmult (3D heat, Q4 space x cG(2) time); achieved HBM GB/s" if args.config == 1 else
@@ -340,10 +404,11 @@ def main():
             "vs_baseline": None, "dtype": "f64" if args.number == "double" else "f32", "data": "synthetic",
             "config": {"workload": (f"3D wave, Q{p} x dG({r}), 80x80x80 cells on [-1,1]^3, Coefficient(1,9,16) per cell, {total_dofs} space-time DoFs "
                                     "= BASELINE configs[3] on one GPU") if args.config == 3 else
-                                   (f"3D heat, Q{p} x cG({r}), {global_nc[0]}x{global_nc[1]}x{global_nc[2]} cells "
+                                   (f"3D heat, Q{p} x cG({r})" + (f" x {args.timesteps_at_once} time steps at once" if args.timesteps_at_once > 1 else "")
+                                    + f", {global_nc[0]}x{global_nc[1]}x{global_nc[2]} cells "
                                     + (f"perturbed ({args.distort} h vertex jitter)" if args.distort else "Cartesian")
                                     + f" slab mesh, {total_dofs} space-time DoFs"
-                                    + (" = BASELINE configs[1]" if (world, n, p, r, args.distort) == (1, 72, 4, 2, 0.0) else "")
+                                    + (" = BASELINE configs[1]" if (world, n, p, r, args.distort, args.timesteps_at_once) == (1, 72, 4, 2, 0.0, 1) else "")
                                     + (" = the BASELINE configs[2] mesh" if (global_nc, p, r, args.distort) == ((144, 144, 144), 4, 2, 0.15) else "")),
                        "n_blocks": nb, "cells_per_gpu": ctx.n_cells,
                        "partition": f"z-slabs x{world}", "kernel": ctx.last_kernel_name,
@@ -357,13 +422,19 @@ def main():
                        # configs[2] mesh type (general-geometry kernel, ~4x the time per cell): the one-GPU point of THIS curve is
                        # `bench.py --gpus 1 --distort 0.15` (weak) or `--gpus 1 --scaling strong --distort 0.15` (strong)
                        "one_gpu_point_of_this_curve": None if world == 1 else
-                       ("bench.py --gpus 1 --distort %g" % args.distort + (" --scaling strong" if args.scaling == "strong" else ""))},
+                       ("bench.py --gpus 1 --distort %g" % args.distort + (" --scaling strong" if args.scaling == "strong" else "")),
+                       # strong scaling: the same mesh on ONE GPU (rank 0, same process, wall clock over a few vmults after the
+                       # timed region) and the speed-up of this N-GPU line over it
+                       "one_gpu_ms_per_step_same_mesh": one_gpu_ms,
+                       "speedup_vs_one_gpu_same_mesh": (one_gpu_ms / ms_per_step) if one_gpu_ms else None,
+                       # what RCCL itself reports for the communicator behind the C-ABI (ncclCommCount)
+                       "rccl_nranks": comm.rccl_nranks if comm is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes of this command "
+                         "traffic_source": (f"{traffic_file}: rocprofv3 --pmc passes of this command with these kernel sources (sha256 checked) "
                                             "(FETCH_SIZE x 2 + WRITE_SIZE), committed, not measured in this run")
-                         if traffic is not None else None,
+                         if traffic is not None else traffic_file,
                          "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

@@ -84,6 +84,8 @@ SIGNATURES = {
     "stfem_comm_get_unique_id": (C.c_int, [_vp]),
     "stfem_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "stfem_comm_destroy": (None, [_vp]),
+    "stfem_comm_available": (C.c_int, []),
+    "stfem_comm_rccl_count": (C.c_int, [_vp]),
     "stfem_comm_rank": (C.c_int, [_vp]),
     "stfem_comm_size": (C.c_int, [_vp]),
     "stfem_comm_last_error": (C.c_char_p, []),

@@ -564,10 +564,25 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
     prm.vol = real(1); // detJ and the weights live in the metric
   }
   prm.experiment = c->env_exp;
-  for (int j0 = 0; j0 < nbo; j0 += MAX_BLOCKS) {
+  // Systems with more blocks than one launch takes are cut into panels (dst += for the later column panels).  On the
+  // pencil path a launch needs two cells per wave - Q4 with seven or eight blocks has one - so those systems
+  // are cut into equal panels of a size the pencil sweep has (Q4 x 8 blocks: 2 x 2 panels of four).
+  int panel = MAX_BLOCKS;
+  if (c->variant == 0 && !general) {
+    const int need = std::min(MAX_BLOCKS, std::max(nbo, nbi));
+    typename PR::PPlan probe;
+    std::memset(&probe, 0, sizeof(probe));
+    if (PR::pencil_geometry(c->p, need, 0, probe) != 0) {
+      int maxp = need;
+      while (maxp > 1 && PR::pencil_geometry(c->p, maxp, 0, probe) != 0) --maxp;
+      const int parts = (need + maxp - 1) / maxp;
+      panel = (need + parts - 1) / parts;
+    }
+  }
+  for (int j0 = 0; j0 < nbo; j0 += panel) {
     bool first = true; // first launch into this row panel overwrites dst unless add
-    for (int i0 = 0; i0 < nbi; i0 += MAX_BLOCKS) {
-      const int tj = std::min(MAX_BLOCKS, nbo - j0), ti = std::min(MAX_BLOCKS, nbi - i0);
+    for (int i0 = 0; i0 < nbi; i0 += panel) {
+      const int tj = std::min(panel, nbo - j0), ti = std::min(panel, nbi - i0);
       bool nonzero = false;
       for (int j = 0; j < tj; ++j)
         for (int i = 0; i < ti; ++i) {
@@ -577,7 +592,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         }
       // the reference skips exact zeros too (operators.h:551,556); a panel may only be skipped
       // if something else still defines dst
-      const bool last_panel = i0 + MAX_BLOCKS >= nbi;
+      const bool last_panel = i0 + panel >= nbi;
       if (!nonzero && (atomic || add || !first || !last_panel)) continue;
       prm.nbo = tj;
       prm.nbi = ti;

@@ -37,6 +37,7 @@ struct Rccl {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr; // optional
   bool ok = false;
 };
 
@@ -68,6 +69,7 @@ const Rccl &rccl()
            bind(h, "ncclCommDestroy", q.CommDestroy) && bind(h, "ncclSend", q.Send) && bind(h, "ncclRecv", q.Recv) &&
            bind(h, "ncclGroupStart", q.GroupStart) && bind(h, "ncclGroupEnd", q.GroupEnd) &&
            bind(h, "ncclAllReduce", q.AllReduce) && bind(h, "ncclGetErrorString", q.GetErrorString);
+    (void)bind(h, "ncclCommCount", q.CommCount);
     return q;
   }();
   return r;
@@ -186,6 +188,13 @@ void stfem_comm_destroy(stfem_comm *c)
   delete c;
 }
 
+int stfem_comm_available(void) { return rccl().ok ? 1 : 0; }
+int stfem_comm_rccl_count(const stfem_comm *c)
+{
+  int n = 0;
+  if (!c || !c->comm || !rccl().CommCount || rccl().CommCount(c->comm, &n) != ncclSuccess) return 0;
+  return n;
+}
 int stfem_comm_rank(const stfem_comm *c) { return c ? c->rank : -1; }
 int stfem_comm_size(const stfem_comm *c) { return c ? c->world : 0; }
 

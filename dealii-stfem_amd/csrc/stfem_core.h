@@ -491,6 +491,70 @@ template <int P, int NBM> struct PencilCore {
     wave_lds_fence();
   }
 
+  // The middle phase for systems of four and more temporal blocks: the input blocks' x-lines are STREAMED (one block
+  // ahead) into the two weighted sums ua = sum_i aK(j,i) u_i, ub = sum_i aM(j,i) u_i instead of being held all at once
+  // (2 x NBM x N registers), and the weights of this lane's output block come from a small LDS table, wrow[2 i] =
+  // aK(j,i) vol, wrow[2 i + 1] = aM(j,i) vol (2 x NBM registers per lane otherwise, for the whole kernel).  The
+  // cell-wise coefficients fK, fM (operators.h:1060-1087) multiply the two sums after the transform.
+  template <class Hook>
+  static __device__ __forceinline__ void middle_stream(const SweepParams &prm, real_t *__restrict__ lds, int cell_in_wave,
+                                                       int blk, int k, bool out_active, bool is_last, real_t lzk,
+                                                       const real_t *__restrict__ wrow, real_t fK, real_t fM, Hook &&row_hook)
+  {
+    real_t *cb_lds = lds + cb_offset(cell_in_wave, blk);
+    const int oz = opaque_zero();
+    const real_t *W = prm.fd_W + oz, *lx = prm.fd_lx + oz, *ly = prm.fd_ly + oz;
+    const int nbi = prm.nbi;
+    asm volatile("" : "+v"(lzk), "+v"(fK), "+v"(fM));
+    STFEM_UNROLL
+    for (int y = 0; y < N; ++y) {
+      row_hook(y);
+      int base = cb_offset(cell_in_wave, 0) + y * N + k;
+      asm volatile("" : "+v"(base));
+      real_t ua[N], ub[N], v[2][N], w[2][2];
+      STFEM_UNROLL
+      for (int x = 0; x < N; ++x) {
+        ua[x] = ub[x] = real_t(0);
+        v[0][x] = lds[base + x * PS];
+      }
+      w[0][0] = wrow[0];
+      w[0][1] = wrow[1];
+      STFEM_UNROLL
+      for (int i = 0; i < NBM; ++i) {
+        if (i < nbi) { // (wave-uniform)
+          if (i + 1 < NBM && i + 1 < nbi) {
+            STFEM_UNROLL
+            for (int x = 0; x < N; ++x) v[(i + 1) & 1][x] = lds[base + (i + 1) * CPW * CBS + x * PS];
+            w[(i + 1) & 1][0] = wrow[2 * (i + 1)];
+            w[(i + 1) & 1][1] = wrow[2 * (i + 1) + 1];
+          }
+          STFEM_UNROLL
+          for (int x = 0; x < N; ++x) {
+            ua[x] = fma(w[i & 1][0], v[i & 1][x], ua[x]);
+            ub[x] = fma(w[i & 1][1], v[i & 1][x], ub[x]);
+          }
+        }
+      }
+      const real_t sy = lzk + ly[y];
+      real_t ta[N], tb[N], acc[N], r[N];
+      fd_forward<N>(W, ua, ta);
+      fd_forward<N>(W, ub, tb);
+      STFEM_UNROLL
+      for (int x = 0; x < N; ++x) acc[x] = fma(fK * (sy + lx[x]), ta[x], fM * tb[x]);
+      fd_backward<N>(W, acc, r);
+      pin(r);
+      if (out_active) {
+        STFEM_UNROLL
+        for (int x = 0; x < P; ++x) cb_lds[x * PS + y * N + k] = r[x];
+        asm volatile("" ::: "memory"); // the neighbour's own x = 0 write precedes the add below
+        if (is_last) cb_lds[P * PS + y * N + k] = r[P];
+        else atomicAdd(&cb_lds[CBS + y * N + k], r[P]); // the next cell of the row, same block
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+  }
+
   // plane of lane i <- LDS, modal -> nodal in y (all columns), then row by row in z;
   // row_done(y, r) receives the finished row y of the result plane, r[z], as soon as it is complete
   template <class RowDone>

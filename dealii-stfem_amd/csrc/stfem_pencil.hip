@@ -106,9 +106,12 @@ template <int P, int NBM, int TY> struct PencilGeom {
   static constexpr int WY = PENCIL_WY;
   static constexpr int NT = 64 * WY;
   static constexpr int MAIL = 64 * N; // one mailbox buffer: [z][lane]
-  // transpose slabs, mailboxes, hand-over counters + tile number (dynamic LDS: above the 64 KB static limit for Q4)
+  // systems of four and more blocks keep the temporal weights in an LDS table [output block][input block][K, M]
+  static constexpr bool WLDS = NBM >= 4;
+  static constexpr int WTAB = WLDS ? 2 * NBM * NBM : 0;
+  // transpose slabs, mailboxes, hand-over counters + tile number, weight table (dynamic LDS: above the 64 KB static limit for Q4)
   static constexpr size_t LDS_BYTES =
-    sizeof(real_t) * (size_t(WY) * PencilCore<P, NBM>::LDS_PER_WAVE + size_t(WY - 1) * 2 * MAIL) + sizeof(int) * (2 * WY + 4);
+    sizeof(real_t) * (size_t(WY) * PencilCore<P, NBM>::LDS_PER_WAVE + size_t(WY - 1) * 2 * MAIL + WTAB) + sizeof(int) * (2 * WY + 4);
 };
 
 
@@ -144,6 +147,16 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   volatile int *flags = reinterpret_cast<volatile int *>(mail_base + (WY - 1) * 2 * PG::MAIL);
   volatile int *prod = flags, *cons = flags + WY;
   volatile int *s_tile = flags + 2 * WY;
+  // weight table of the systems with four and more blocks (read-only after the first barrier of the tile loop)
+  real_t *wtab = const_cast<real_t *>(reinterpret_cast<volatile real_t *>(flags + 2 * WY + 4));
+  if constexpr (PG::WLDS) {
+    for (int e = threadIdx.x; e < NBM * NBM; e += PG::NT) {
+      const int j = e / NBM, q = e % NBM;
+      const bool ok = j < prm.nbo && q < prm.nbi;
+      wtab[2 * e] = ok ? prm.alpha[j * prm.nbi + q] * prm.vol : real_t(0);
+      wtab[2 * e + 1] = ok ? prm.beta[j * prm.nbi + q] * prm.vol : real_t(0);
+    }
+  }
   auto flag_wait = [&](volatile int *f, int target) {
     while (*f < target) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
@@ -216,13 +229,16 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   real_t lzk = prm.fd_lz[0];
   STFEM_UNROLL
   for (int m = 1; m < N; ++m) lzk = i == m ? prm.fd_lz[m] : lzk;
-  // temporal weights of this lane's output block (cell volume folded in)
-  real_t aK0[NBM], aM0[NBM];
-  STFEM_UNROLL
-  for (int q = 0; q < NBM; ++q) {
-    const bool ok = blk < prm.nbo && q < prm.nbi;
-    aK0[q] = ok ? prm.alpha[blk * prm.nbi + q] * prm.vol : real_t(0);
-    aM0[q] = ok ? prm.beta[blk * prm.nbi + q] * prm.vol : real_t(0);
+  // temporal weights of this lane's output block (cell volume folded in); in the LDS table for four and more blocks
+  constexpr int NW = PG::WLDS ? 1 : NBM;
+  real_t aK0[NW], aM0[NW];
+  if constexpr (!PG::WLDS) {
+    STFEM_UNROLL
+    for (int q = 0; q < NBM; ++q) {
+      const bool ok = blk < prm.nbo && q < prm.nbi;
+      aK0[q] = ok ? prm.alpha[blk * prm.nbi + q] * prm.vol : real_t(0);
+      aM0[q] = ok ? prm.beta[blk * prm.nbi + q] * prm.vol : real_t(0);
+    }
   }
 
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;
@@ -350,11 +366,13 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
         for (int z = 0; z < N; ++z)
           if (constrained_dof(y, z)) PA[y * N + z] = real_t(0);
       }
-      real_t aK[NBM], aM[NBM];
-      STFEM_UNROLL
-      for (int q = 0; q < NBM; ++q) {
-        aK[q] = COEF ? aK0[q] * fK : aK0[q];
-        aM[q] = COEF ? aM0[q] * fM : aM0[q];
+      real_t aK[NW], aM[NW];
+      if constexpr (!PG::WLDS) {
+        STFEM_UNROLL
+        for (int q = 0; q < NBM; ++q) {
+          aK[q] = COEF ? aK0[q] * fK : aK0[q];
+          aM[q] = COEF ? aM0[q] * fM : aM0[q];
+        }
       }
 
       real_t *cb_lds = lds + Core::cb_offset(c, blk);
@@ -375,7 +393,11 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
           load_coef(cell0 + (more_y ? int64_t(prm.ncx) * (cyl + 1) + cells_per_layer * layer : cells_per_layer * (layer + 1)), fK, fM);
       };
       PTL(2);
-      if (!(PEX & 4)) Core::middle(prm, lds, c, blk, i, lf & LF_OUT, lf & LF_LAST, lzk, aK, aM, prefetch_row);
+      if constexpr (PG::WLDS) {
+        // (fK, fM are the CURRENT cell's: the hook overwrites them with the next cell's during the phase)
+        const real_t cK = COEF ? fK : real_t(1), cM = COEF ? fM : real_t(1);
+        Core::middle_stream(prm, lds, c, blk, i, lf & LF_OUT, lf & LF_LAST, lzk, wtab + blk * (2 * NBM), cK, cM, prefetch_row);
+      } else if (!(PEX & 4)) Core::middle(prm, lds, c, blk, i, lf & LF_OUT, lf & LF_LAST, lzk, aK, aM, prefetch_row);
       else {
         STFEM_UNROLL
         for (int y = 0; y < N; ++y) prefetch_row(y);
@@ -636,15 +658,17 @@ template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, c
 
 // cell rows per pencil: two, except where the second set of z-carry registers makes the kernel spill
 // (Q4 with three temporal blocks; tools/check_async.py fails the build if an instantiation spills)
-constexpr int pencil_ty(int p, int nbm) { return (p == 4 && nbm >= 3) ? 1 : 2; }
+constexpr int pencil_ty(int p, int nbm) { return (p == 4 && nbm == 3) ? 1 : 2; }
 
 template <int P, int NBM> int launch_pencil_t(const SweepParams &prm, const PencilPlan &pp, hipStream_t st)
 {
-  if (Geometry<P, NBM>::CELLS_PER_WAVE < 2) return -2; // needs the halo slot and at least one owned cell
-  if (pp.ty == 1) return launch_pencil_ty<P, NBM, 1>(prm, pp, st);
-  if constexpr (pencil_ty(P, NBM) == 2)
-    if (pp.ty == 2) return launch_pencil_ty<P, NBM, 2>(prm, pp, st);
-  return -2;
+  if constexpr (Geometry<P, NBM>::CELLS_PER_WAVE < 2) return -2; // needs the halo slot and at least one owned cell
+  else {
+    if (pp.ty == 1) return launch_pencil_ty<P, NBM, 1>(prm, pp, st);
+    if constexpr (pencil_ty(P, NBM) == 2)
+      if (pp.ty == 2) return launch_pencil_ty<P, NBM, 2>(prm, pp, st);
+    return -2;
+  }
 }
 
 } // namespace
@@ -660,7 +684,7 @@ int STFEM_PASTE(launch_pencil_p, STFEM_PENCIL_P)(const SweepParams &prm, const P
 #ifdef STFEM_QUICK
   STFEM_CASE(2)
 #else
-  STFEM_CASE(1) STFEM_CASE(2) STFEM_CASE(3)
+  STFEM_CASE(1) STFEM_CASE(2) STFEM_CASE(3) STFEM_CASE(4) STFEM_CASE(6) STFEM_CASE(8)
 #endif
 #undef STFEM_CASE
   return -2;
@@ -689,10 +713,8 @@ int pencil_geometry(int p, int nbm, int ty, PencilPlan &plan)
   if (p < 1 || p > 4) return -2;
   nbm = round_nbm(nbm);
   if (ty < 1 || ty > pencil_ty(p, nbm)) ty = pencil_ty(p, nbm);
-  // more than three temporal blocks per launch: the middle phase of the core (one x-line of every
-  // input block in flight per lane) no longer fits 256 VGPRs without spilling; the tile variant
-  // handles those systems
-  if (nbm > 3) return -2;
+  // (four and more temporal blocks per launch: PencilCore::middle_stream; the caller cuts systems for which
+  // fewer than two cells fit a wave - Q4 with seven or eight blocks - into smaller panels)
   const int cpw = (64 / (p + 1)) / nbm;
   if (cpw < 2) return -2;
   plan.cpw = cpw;

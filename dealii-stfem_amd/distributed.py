@@ -109,6 +109,17 @@ class Communicator:
     instead of torch.distributed.  `bcast(bytes_or_None) -> bytes` carries the 128-byte id from rank 0
     to the others (MPI_Bcast on the deal.II side; torch.distributed / gloo in bench.py and the tests)."""
 
+    @staticmethod
+    def available():
+        """RCCL can be bound in this process.  Ask on every rank and agree (all-reduce MIN) BEFORE any rank constructs a
+        Communicator: the constructor is collective (broadcast of the id, ncclCommInitRank)."""
+        from . import lib
+        return bool(lib().stfem_comm_available())
+
+    @property
+    def rccl_nranks(self):
+        return int(self._L.stfem_comm_rccl_count(self._h)) if getattr(self, "_h", None) else 0
+
     def __init__(self, rank, world, device, bcast):
         import ctypes as C
         from . import lib, _check

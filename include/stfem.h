@@ -174,6 +174,10 @@ typedef struct stfem_comm stfem_comm;
 int stfem_comm_get_unique_id(void *id);
 int stfem_comm_create(const void *id, int rank, int world, int device, stfem_comm **out);
 void stfem_comm_destroy(stfem_comm *comm);
+/* 1 if an RCCL could be bound in this process (ask on EVERY rank and agree before any rank enters the collective
+ * stfem_comm_create); the rank count RCCL itself reports for the communicator (ncclCommCount; 0 if unknown) */
+int stfem_comm_available(void);
+int stfem_comm_rccl_count(const stfem_comm *comm);
 int stfem_comm_rank(const stfem_comm *comm);
 int stfem_comm_size(const stfem_comm *comm);
 const char *stfem_comm_last_error(void);

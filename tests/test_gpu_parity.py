@@ -170,6 +170,10 @@ def test_vs_oracle(case, stfem, oracle_mod):
     nb = Alpha.shape[0]
     X = random_blocks(nb, ctx.n_dofs)
     assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    # every Cartesian system runs the pencil sweep since round 3 (4 - 8 blocks: PencilCore::middle_stream; Q4 x 8
+    # blocks and systems of more than eight blocks in panels), unless STFEM_VARIANT asks for another kernel
+    if not os.environ.get("STFEM_VARIANT"):
+        assert ctx.last_kernel_name.startswith("st_sweep_pencil"), ctx.last_kernel_name
     assert rel(apply(stfem, ctx, Alpha, Beta, X, transpose=True),
                orc.st_vmult(Alpha, Beta, X, transpose=True)) < TOL
     # vmult_slice / vmult_slice_add (rhs assembly, operators.h:377-382, 586-611)
@@ -204,6 +208,30 @@ def test_wave_matrices_and_coefficient(stfem, oracle_mod):
     ctx.evaluate_coefficient(None, which=1)
     orc.set_coefficient(0, None); orc.set_coefficient(1, None)
     assert rel(apply(stfem, ctx, A, B, X), orc.st_vmult(A, B, X)) < TOL
+
+
+@pytest.mark.parametrize("p,nc,tt,r,ns", [(2, (11, 6, 5), "CGP", 1, 4), (4, (8, 5, 3), "CGP", 2, 2), (3, (7, 4, 5), "DG", 2, 2), (1, (9, 8, 7), "DG", 1, 4),
+                                          (4, (5, 3, 3), "CGP", 4, 2)],
+                         ids=["Q2-CGP1x4", "Q4-CGP2x2", "Q3-DG2x2", "Q1-DG1x4", "Q4-CGP4x2"])
+def test_many_blocks_with_cell_coefficients(p, nc, tt, r, ns, stfem, oracle_mod):
+    """4 / 6 / 8 temporal blocks (the reference's n_timesteps_at_once systems, fe_time.h:373-402) with cell-wise
+    coefficients on K and M (operators.h:1060-1087): the streamed middle phase of the pencil sweep with its LDS weight table."""
+    t = stfem.CGP if tt == "CGP" else stfem.DG
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(t, r, 0.03, ns)
+    verts = stfem.mesh_vertices(nc, (0, 0, 0), (1.0, 0.7, 1.3))
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts, dirichlet_mask=0b011011)
+    orc = oracle_mod.Oracle(p, nc, verts, 0b011011)
+    rng = np.random.default_rng(17)
+    cl, cm = rng.uniform(0.5, 3.0, ctx.n_cells), rng.uniform(0.5, 2.0, ctx.n_cells)
+    ctx.evaluate_coefficient(cl, which=1); ctx.evaluate_coefficient(cm, which=0)
+    orc.set_coefficient(1, np.repeat(cl, (p + 1) ** 3)); orc.set_coefficient(0, np.repeat(cm, (p + 1) ** 3))
+    X = random_blocks(Alpha.shape[0], ctx.n_dofs)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X), orc.st_vmult(Alpha, Beta, X)) < TOL
+    if not os.environ.get("STFEM_VARIANT"):
+        assert ctx.last_kernel_name.startswith("st_sweep_pencil"), ctx.last_kernel_name
+    assert rel(apply(stfem, ctx, Alpha, Beta, X, transpose=True), orc.st_vmult(Alpha, Beta, X, transpose=True)) < TOL
+    ref = orc.st_vmult(Alpha, Beta, X)
+    assert rel(apply(stfem, ctx, Alpha, Beta, X, add_to=ref), 2 * ref) < TOL  # dst += (compiler-tracked loads)
 
 
 def test_rectangular_and_errors(stfem, oracle_mod):
@@ -328,7 +356,7 @@ def test_fp32_golden_fixture(name, stfem, golden_dir):
     assert rel(d, g["diagM"]) < TOL32
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6]],
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6], CASES[8], CASES[9]],
                          ids=lambda c: f"f32-Q{c[0]}-{c[5]}{c[6]}x{c[7]}")
 def test_fp32_vs_oracle(case, stfem, oracle_mod):
     p, nc, lo, up, mask, tt, r, ns, tau = case

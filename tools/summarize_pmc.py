@@ -32,7 +32,7 @@ try:
         acc = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            if "stfem" in k and ("st_sweep" in k or "fixup" in k):  # the kernels of a vmult, not the set-up ones
+            if "stfem" in k and ("st_sweep" in k or "fixup" in k or "st_general" in k):  # the kernels of a vmult, not the set-up ones
                 acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
         for k, cs in acc.items():
             for c, v in cs.items():
@@ -45,7 +45,9 @@ try:
         write = sum(s for (s, _) in per["WRITE_SIZE"].values()) / calls
         kern = ("st_sweep_pencil" if any("sweep_pencil" in k for k in per["FETCH_SIZE"]) else
                 "st_sweep_cart_tile" if any("cart_tile" in k for k in per["FETCH_SIZE"]) else "st_sweep_cart_atomic")
-        json.dump({"kernel": kern, "fetch_kb_per_vmult": fetch, "write_kb_per_vmult": write,
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import sweep_source_hash
+        json.dump({"kernel": kern, "fetch_kb_per_vmult": fetch, "write_kb_per_vmult": write, "sources_sha256": sweep_source_hash(),
                    "note": "sum over the kernels of one stfem_st_vmult (sweep launch(es) + fix-up)"},
                   open(os.path.join(d, "traffic.json"), "w"), indent=1)
         print("traffic.json:", fetch, write)
