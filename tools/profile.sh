@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT $SUM
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline $@"
+ARGS="--steps ${STEPS:-60} --warmup ${WARMUP:-10} --no-cpu-baseline $@"  # >= 50 back-to-back launches: the kernel average is the throttled steady state
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $SUM/kernel_stats.csv \;
 # separate counter passes (never combined with tracing domains other than kernel-trace)
