@@ -76,6 +76,9 @@ SIGNATURES = {
     "stfem_diagonal": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
     "stfem_tensorproduct_add": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp]),
     "stfem_dot": (C.c_int, [_vp, _vp, _vp, C.c_int64, _dp, _vp]),
+    "stfem_multi_dot": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _vp]),
+    "stfem_multi_axpy": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_vp), _vp, _vp]),
+    "stfem_orthogonalize": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _dp, _vp]),
     "stfem_diagonal_inverse": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
     "stfem_st_diagonal": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _vp, _vp]),
     "stfem_plane_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
@@ -156,6 +159,10 @@ SIGNATURES = {
     "stfem_stokes_st_vmult_slice_add": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.POINTER(_vp),
                                                   _vp, _vp, _vp]),
     "stfem_stokes_last_hip_error": (C.c_char_p, []),
+    "stfem_stokes_set_weak_boundaries": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "stfem_stokes_n_face_points": (C.c_int64, [_vp]),
+    "stfem_stokes_face_points": (C.c_int, [_vp, _dp]),
+    "stfem_stokes_nitsche_rhs": (C.c_int, [_vp, _dp, _vp, _vp, _vp]),
     "stfem_strerror": (C.c_char_p, [C.c_int]),
     "stfem_last_hip_error": (C.c_char_p, []),
     "stfem_last_kernel_name": (C.c_char_p, [_vp]),
@@ -492,6 +499,34 @@ def dot(ctx, a, b, n_own=0, stream=None):
     return out.value
 
 
+def multi_dot(ctx, vs, w, n_own=0, stream=None):
+    """[<v_i, w>]: the inner products of a Gram-Schmidt step in one pass over w per eight vectors (deterministic reductions)"""
+    k = len(vs)
+    out = np.zeros(k)
+    arr = (_vp * k)(*[v._h for v in vs])
+    _check(lib().stfem_multi_dot(ctx._h, k, arr, w._h, n_own, _p(out), stream), "stfem_multi_dot")
+    return out
+
+
+def multi_axpy(ctx, coef, xs, y, stream=None):
+    """y += sum_i coef_i x_i"""
+    k = len(xs)
+    c = np.ascontiguousarray(coef, dtype=np.float64)
+    assert c.size == k
+    arr = (_vp * k)(*[v._h for v in xs])
+    _check(lib().stfem_multi_axpy(ctx._h, k, _p(c), arr, y._h, stream), "stfem_multi_axpy")
+
+
+def orthogonalize(ctx, vs, w, n_own=0, stream=None):
+    """one classical Gram-Schmidt pass on the device: returns (h = V^T w, <w, w> after w -= V h)"""
+    k = len(vs)
+    h = np.zeros(k)
+    n2 = C.c_double(0.0)
+    arr = (_vp * k)(*[v._h for v in vs])
+    _check(lib().stfem_orthogonalize(ctx._h, k, arr, w._h, n_own, _p(h), C.byref(n2), stream), "stfem_orthogonalize")
+    return h, n2.value
+
+
 # ------------------------------------------------------------------ space-time multigrid (8 f-2)
 
 def get_poly_mg_sequence(k_max, k_min, sequence_type="decrease_by_one"):
@@ -610,7 +645,10 @@ class StokesMatrixFreeOperator:
     torch.Tensor.data_ptr()): velocity 3 * n_velocity doubles (component-major), pressure n_pressure."""
 
     def __init__(self, ncell, vertices=None, lower=(0, 0, 0), upper=(1, 1, 1), dirichlet_mask=63,
-                 viscosity=1.0, velocity_degree=2, device=0):
+                 viscosity=1.0, velocity_degree=2, device=0, weak_boundary_ids=(), outflow_boundary_ids=(),
+                 penalty1=20.0, penalty2=10.0):
+        """weak_boundary_ids / outflow_boundary_ids: boundary ids 0..5 (face 2 d + s) as in the reference's constructor
+        (operators.h:1206-1211); penalty1 / penalty2: its Nitsche penalties (gamma1 = viscosity penalty1, gamma2 = penalty2)."""
         m = _MeshDesc()
         self.ncell = tuple(int(v) for v in ncell)
         m.ncell[:] = self.ncell
@@ -628,11 +666,29 @@ class StokesMatrixFreeOperator:
         self._h = h
         self.n_velocity = lib().stfem_stokes_n_velocity_dofs(h)
         self.n_pressure = lib().stfem_stokes_n_pressure_dofs(h)
+        self.weak_mask = sum(1 << int(f) for f in set(weak_boundary_ids))
+        self.outflow_mask = sum(1 << int(f) for f in set(outflow_boundary_ids))
+        if self.weak_mask or self.outflow_mask:
+            _check(lib().stfem_stokes_set_weak_boundaries(h, self.weak_mask, self.outflow_mask, penalty1, penalty2),
+                   "stfem_stokes_set_weak_boundaries")
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.stfem_stokes_destroy(self._h)
             self._h = None
+
+    def face_points(self):
+        """quadrature points of the weak faces [point][3], where the Dirichlet function is evaluated (operators.h:1911-1914)"""
+        out = np.zeros((lib().stfem_stokes_n_face_points(self._h), 3))
+        _check(lib().stfem_stokes_face_points(self._h, _p(out)), "stfem_stokes_face_points")
+        return out
+
+    def nitsche_rhs(self, g_at_face_points, dst_u, dst_p, stream=None):
+        """StokesNitscheMatrixFreeOperator::vmult(dst) (operators.h:1833-1849): dst += boundary functional of the Dirichlet data"""
+        g = np.ascontiguousarray(g_at_face_points, dtype=np.float64)
+        assert g.shape == (lib().stfem_stokes_n_face_points(self._h), 3)
+        _check(lib().stfem_stokes_nitsche_rhs(self._h, _p(g), getattr(dst_u, "ptr", dst_u), getattr(dst_p, "ptr", dst_p), stream),
+               "stfem_stokes_nitsche_rhs")
 
     def initialize_dof_vector(self, variable, host=None):
         """Device vector of `variable` (0 velocity, 1 pressure) as a StokesVector; optionally filled."""

@@ -200,7 +200,7 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
   c->env_pencil_ty = env_int("STFEM_PENCIL_TY", 0);
   c->env_pencil_lz = env_int("STFEM_PENCIL_LZ", 0);
   c->env_timeline = getenv("STFEM_TIMELINE");
-  if (hipMalloc(&c->d_scratch, 4096) != hipSuccess) {
+  if (hipMalloc(&c->d_scratch, sizeof(double) * (256 + 8 * 512)) != hipSuccess) { // reduction results [256] + partials [DOT_VECS][DOT_GRID]
     delete c;
     return STFEM_ERR_OUT_OF_MEMORY;
   }
@@ -938,18 +938,108 @@ int stfem_tensorproduct_add(stfem_ctx *c, int nrows, int ncols, const double *A,
 }
 
 extern "C++" {
-// local dot product, accumulated in double for both precisions
+// Local inner products, accumulated in double for both precisions, in TWO STAGES with a fixed summation order (bitwise
+// reproducible: round 2 finished with a device atomic): every workgroup of stage 1 writes its partial sums, one
+// workgroup of stage 2 adds them in index order.  One launch pair handles up to DOT_VECS left-hand vectors against the
+// same right-hand vector over all spatial blocks (the Gram-Schmidt step of the Krylov solvers: k inner products, one pass
+// over w per group of eight, one read-back).
+constexpr int DOT_VECS = 8, DOT_GRID = 512;
+struct DotArgs {
+  const void *a[DOT_VECS][MAX_BLOCKS];
+  const void *b[MAX_BLOCKS];
+  int nvec, nblk;
+};
 template <typename T>
-__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T *a, const T *b, double *out)
+__global__ __launch_bounds__(256) void multi_dot_kernel(int64_t n, const DotArgs args, double *partial /* [nvec][gridDim.x] */)
 {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    s = fma(double(a[i]), double(b[i]), s);
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __shared__ double red[DOT_VECS][4];
+  double s[DOT_VECS];
+#pragma unroll
+  for (int v = 0; v < DOT_VECS; ++v) s[v] = 0.0;
+  for (int blk = 0; blk < args.nblk; ++blk) {
+    const T *b = static_cast<const T *>(args.b[blk]);
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+      const double w = double(b[i]);
+#pragma unroll
+      for (int v = 0; v < DOT_VECS; ++v)
+        if (v < args.nvec) s[v] = fma(double(static_cast<const T *>(args.a[v][blk])[i]), w, s[v]);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < DOT_VECS; ++v) {
+    for (int off = 32; off > 0; off >>= 1) s[v] += __shfl_down(s[v], off, 64);
+    if ((threadIdx.x & 63) == 0) red[v][threadIdx.x >> 6] = s[v];
+  }
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x < unsigned(args.nvec)) {
+    const int v = threadIdx.x;
+    partial[v * gridDim.x + blockIdx.x] = (red[v][0] + red[v][1]) + (red[v][2] + red[v][3]);
+  }
+}
+// stage 2: out[v] = sum of the partials of vector v in index order (a tree with fixed shape)
+__global__ __launch_bounds__(256) void dot_finish_kernel(int nvec, int nparts, const double *partial, double *out)
+{
+  __shared__ double red[256];
+  for (int v = 0; v < nvec; ++v) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partial[v * nparts + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (int(threadIdx.x) < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[v] = red[0];
+    __syncthreads();
+  }
+}
+struct MultiAxpyArgs {
+  const void *x[DOT_VECS][MAX_BLOCKS];
+  void *y[MAX_BLOCKS];
+  double coef[DOT_VECS];
+  const double *dcoef; // coefficients on the device (sign applied below), or nullptr: coef
+  double sign;
+  int nvec;
+};
+// y += sign * sum_v coef_v x_v on every spatial block (blockIdx.y)
+template <typename T> __global__ __launch_bounds__(256) void multi_axpy_kernel(int64_t n, const MultiAxpyArgs args)
+{
+  const int blk = blockIdx.y;
+  T *y = static_cast<T *>(args.y[blk]);
+  double c[DOT_VECS];
+#pragma unroll
+  for (int v = 0; v < DOT_VECS; ++v) c[v] = v < args.nvec ? args.sign * (args.dcoef ? args.dcoef[v] : args.coef[v]) : 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    double acc = double(y[i]);
+#pragma unroll
+    for (int v = 0; v < DOT_VECS; ++v)
+      if (v < args.nvec) acc = fma(c[v], double(static_cast<const T *>(args.x[v][blk])[i]), acc);
+    y[i] = T(acc);
+  }
+}
+
+// d_out[0 .. k): <a_i, b> over the first n_own entries of every block; stays on the device
+static int multi_dot_device(stfem_ctx *c, int k, const stfem_vec *const *as, const stfem_vec *b, int64_t n_own, double *d_out, hipStream_t st)
+{
+  if (b->nb > MAX_BLOCKS) return STFEM_ERR_UNSUPPORTED;
+  const int grid = (int)std::min<int64_t>((n_own + 255) / 256, DOT_GRID);
+  double *partial = c->d_scratch + 256; // [DOT_VECS][DOT_GRID]
+  (void)hipGetLastError();
+  for (int k0 = 0; k0 < k; k0 += DOT_VECS) {
+    DotArgs args;
+    std::memset(&args, 0, sizeof(args));
+    args.nvec = std::min(DOT_VECS, k - k0);
+    args.nblk = b->nb;
+    for (int j = 0; j < b->nb; ++j) args.b[j] = b->blk[j];
+    for (int v = 0; v < args.nvec; ++v) {
+      if (!as[k0 + v] || as[k0 + v]->nb != b->nb || as[k0 + v]->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+      for (int j = 0; j < b->nb; ++j) args.a[v][j] = as[k0 + v]->blk[j];
+    }
+    if (c->prec) hipLaunchKernelGGL(multi_dot_kernel<float>, dim3(grid), dim3(256), 0, st, n_own, args, partial);
+    else hipLaunchKernelGGL(multi_dot_kernel<double>, dim3(grid), dim3(256), 0, st, n_own, args, partial);
+    hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(256), 0, st, args.nvec, grid, partial, d_out + k0);
+  }
+  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
 }
 
 } // extern "C++"
@@ -960,18 +1050,105 @@ int stfem_dot(stfem_ctx *c, const stfem_vec *a, const stfem_vec *b, int64_t n_ow
   if (n_own <= 0 || n_own > c->ndofs) n_own = c->ndofs;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipMemsetAsync(c->d_scratch, 0, sizeof(double), st));
-  const unsigned grid = (unsigned)std::min<int64_t>((n_own + 255) / 256, 1024);
-  for (int blk = 0; blk < a->nb; ++blk) {
-    if (c->prec)
-      hipLaunchKernelGGL(dot_kernel<float>, dim3(grid), dim3(256), 0, st, n_own, static_cast<const float *>(a->blk[blk]),
-                         static_cast<const float *>(b->blk[blk]), c->d_scratch);
-    else
-      hipLaunchKernelGGL(dot_kernel<double>, dim3(grid), dim3(256), 0, st, n_own, static_cast<const double *>(a->blk[blk]),
-                         static_cast<const double *>(b->blk[blk]), c->d_scratch);
+  if (a->nb > MAX_BLOCKS) { // (vectors of more than eight blocks: eight at a time)
+    double sum = 0.0;
+    for (int j0 = 0; j0 < a->nb; j0 += MAX_BLOCKS) {
+      stfem_vec va = *a, vb = *b;
+      va.nb = vb.nb = std::min(MAX_BLOCKS, a->nb - j0);
+      va.blk.assign(a->blk.begin() + j0, a->blk.begin() + j0 + va.nb);
+      vb.blk.assign(b->blk.begin() + j0, b->blk.begin() + j0 + vb.nb);
+      double part = 0.0;
+      const int rc = stfem_dot(c, &va, &vb, n_own, &part, stream);
+      if (rc != STFEM_OK) return rc;
+      sum += part;
+    }
+    *out = sum;
+    return STFEM_OK;
   }
+  const stfem_vec *as[1] = {a};
+  const int rc = multi_dot_device(c, 1, as, b, n_own, c->d_scratch, st);
+  if (rc != STFEM_OK) return rc == STFEM_ERR_HIP ? hip_fail(hipGetLastError(), "dot") : rc;
   HIP_TRY(hipMemcpyAsync(out, c->d_scratch, sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return STFEM_OK;
+}
+
+int stfem_multi_dot(stfem_ctx *c, int k, const stfem_vec *const *as, const stfem_vec *b, int64_t n_own, double *out, void *stream)
+{
+  if (!c || !as || !b || !out || k < 1 || k > 256 - 8 || b->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (n_own <= 0 || n_own > c->ndofs) n_own = c->ndofs;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = multi_dot_device(c, k, as, b, n_own, c->d_scratch, st);
+  if (rc != STFEM_OK) return rc == STFEM_ERR_HIP ? hip_fail(hipGetLastError(), "multi_dot") : rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_scratch, sizeof(double) * k, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return STFEM_OK;
+}
+
+int stfem_multi_axpy(stfem_ctx *c, int k, const double *coef, const stfem_vec *const *xs, stfem_vec *y, void *stream)
+{
+  if (!c || !coef || !xs || !y || k < 1 || y->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (y->nb > MAX_BLOCKS) return STFEM_ERR_UNSUPPORTED;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 2048);
+  (void)hipGetLastError();
+  for (int k0 = 0; k0 < k; k0 += DOT_VECS) {
+    MultiAxpyArgs args;
+    std::memset(&args, 0, sizeof(args));
+    args.nvec = std::min(DOT_VECS, k - k0);
+    args.sign = 1.0;
+    for (int j = 0; j < y->nb; ++j) args.y[j] = y->blk[j];
+    for (int v = 0; v < args.nvec; ++v) {
+      if (!xs[k0 + v] || xs[k0 + v]->nb != y->nb || xs[k0 + v]->ctx != c || xs[k0 + v] == y) return STFEM_ERR_INVALID_ARGUMENT;
+      args.coef[v] = coef[k0 + v];
+      for (int j = 0; j < y->nb; ++j) args.x[v][j] = xs[k0 + v]->blk[j];
+    }
+    if (c->prec) hipLaunchKernelGGL(multi_axpy_kernel<float>, dim3(grid, y->nb), dim3(256), 0, st, c->ndofs, args);
+    else hipLaunchKernelGGL(multi_axpy_kernel<double>, dim3(grid, y->nb), dim3(256), 0, st, c->ndofs, args);
+  }
+  return hipGetLastError() == hipSuccess ? STFEM_OK : hip_fail(hipGetLastError(), "multi_axpy");
+}
+
+// One classical Gram-Schmidt pass of w against v_0 .. v_{k-1} entirely on the device: h = V^T w (two-stage reduction),
+// w -= V h with the coefficients read from device memory, h copied to the host at the end (one synchronisation).
+int stfem_orthogonalize(stfem_ctx *c, int k, const stfem_vec *const *vs, stfem_vec *w, int64_t n_own, double *h_out, double *norm2_out,
+                        void *stream)
+{
+  if (!c || !vs || !w || !h_out || k < 1 || k > 256 - 8 || w->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (w->nb > MAX_BLOCKS) return STFEM_ERR_UNSUPPORTED;
+  if (n_own <= 0 || n_own > c->ndofs) n_own = c->ndofs;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = multi_dot_device(c, k, vs, w, n_own, c->d_scratch, st);
+  if (rc != STFEM_OK) return rc == STFEM_ERR_HIP ? hip_fail(hipGetLastError(), "orthogonalize") : rc;
+  const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 2048);
+  for (int k0 = 0; k0 < k; k0 += DOT_VECS) {
+    MultiAxpyArgs args;
+    std::memset(&args, 0, sizeof(args));
+    args.nvec = std::min(DOT_VECS, k - k0);
+    args.sign = -1.0;
+    args.dcoef = c->d_scratch + k0;
+    for (int j = 0; j < w->nb; ++j) args.y[j] = w->blk[j];
+    for (int v = 0; v < args.nvec; ++v) {
+      if (vs[k0 + v] == w) return STFEM_ERR_ALIAS;
+      for (int j = 0; j < w->nb; ++j) args.x[v][j] = vs[k0 + v]->blk[j];
+    }
+    if (c->prec) hipLaunchKernelGGL(multi_axpy_kernel<float>, dim3(grid, w->nb), dim3(256), 0, st, c->ndofs, args);
+    else hipLaunchKernelGGL(multi_axpy_kernel<double>, dim3(grid, w->nb), dim3(256), 0, st, c->ndofs, args);
+  }
+  if (norm2_out) { // <w, w> after the projection, in the slot behind the coefficients
+    const stfem_vec *ws[1] = {w};
+    rc = multi_dot_device(c, 1, ws, w, n_own, c->d_scratch + k, st);
+    if (rc != STFEM_OK) return rc == STFEM_ERR_HIP ? hip_fail(hipGetLastError(), "orthogonalize") : rc;
+  }
+  if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "orthogonalize");
+  std::vector<double> host(size_t(k) + 1);
+  HIP_TRY(hipMemcpyAsync(host.data(), c->d_scratch, sizeof(double) * (k + (norm2_out ? 1 : 0)), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < k; ++i) h_out[i] = host[i];
+  if (norm2_out) *norm2_out = host[k];
   return STFEM_OK;
 }
 

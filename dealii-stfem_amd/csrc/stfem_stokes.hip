@@ -396,6 +396,229 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   }
 }
 
+
+// ---- boundary faces of the linear operator (LoopType::Full, reference include/operators.h:1640-1741) ----
+// Weak (Nitsche) faces: v <- -nu grad u n + p n + gamma1/h u + gamma2/h n (u.n), dv/dn <- -nu u, q <- -u.n with
+// gamma1 = nu penalty1, gamma2 = penalty2 (1220-1221) and h = sqrt(face area) (get_h_face, 184-209); outflow faces add
+// nothing to the linear operator (1680-1711: the back-flow term carries a factor 0.0, the rest is nonlinear-only).
+// The same kernel evaluates StokesNitscheMatrixFreeOperator::vmult (1898-1940): the functional of the Dirichlet data g.
+// One half-wave per boundary CELL (a cell on several weak faces is handled once, by its lowest face, for all of them);
+// eight colour launches after the cell loop's, plain read-add-write: no atomics, reproducible.
+struct BoundaryParams {
+  int weak_mask;
+  double gamma1, gamma2;
+  int foff[7];             // first work item (cell of a face, t1 fastest) of every face, [6] = total
+  const double *g;         // rhs mode: Dirichlet data at the face quadrature points [point][3]; nullptr: operator mode
+  double Eu[6], EDu[6], Ep[4]; // end-point tables [s * n + a]: FE_Q(2) values / derivatives, FE_Q(1) values at 0 and 1
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams prm, const BoundaryParams bp)
+{
+  __shared__ double tS[9], tD[9], tP[6], tE[6], tED[6], tEP[4], tX[3], tW[3];
+  __shared__ double sX[8][89], sF[8][9][7], sG[8][9][12], sJ[8][9];
+  if (threadIdx.x < 9) { tS[threadIdx.x] = prm.Su[threadIdx.x]; tD[threadIdx.x] = prm.Du[threadIdx.x]; }
+  if (threadIdx.x < 6) { tP[threadIdx.x] = prm.Sp[threadIdx.x]; tE[threadIdx.x] = bp.Eu[threadIdx.x]; tED[threadIdx.x] = bp.EDu[threadIdx.x]; }
+  if (threadIdx.x < 4) tEP[threadIdx.x] = bp.Ep[threadIdx.x];
+  if (threadIdx.x < 3) { tX[threadIdx.x] = prm.xq[threadIdx.x]; tW[threadIdx.x] = prm.wq[threadIdx.x]; }
+  __syncthreads();
+  const int slot = threadIdx.x >> 5, t32 = threadIdx.x & 31;
+  const bool lane27 = t32 < 27;
+  const int t = lane27 ? t32 : 0;
+  const int a = t % 3, b = (t / 3) % 3, c = t / 9;
+  const bool pnode = lane27 && a < 2 && b < 2 && c < 2;
+  const int nc[3] = {prm.ncx, prm.ncy, prm.ncz};
+  double *X = sX[slot];
+  for (long long item = (long long)blockIdx.x * 8 + slot; item - slot < bp.foff[6]; item += (long long)gridDim.x * 8) {
+    // (all half-waves of the workgroup run the same number of rounds: nothing below is a workgroup barrier, but keep it uniform)
+    bool ok = item < bp.foff[6];
+    int f0 = 0;
+    for (int f = 0; f < 6; ++f)
+      if (ok && item >= bp.foff[f] && item < bp.foff[f + 1]) f0 = f;
+    int cc[3] = {0, 0, 0};
+    {
+      const int d = f0 >> 1, s = f0 & 1, t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+      const long long e = ok ? item - bp.foff[f0] : 0;
+      cc[d] = s ? nc[d] - 1 : 0;
+      cc[t1] = int(e % nc[t1]);
+      cc[t2] = int(e / nc[t1]);
+    }
+    const int cx = cc[0], cy = cc[1], cz = cc[2];
+    ok = ok && ((cx & 1) + 2 * (cy & 1) + 4 * (cz & 1)) == prm.colour;
+    // the cell's weak faces; it is handled by the lowest of them
+    int faces = 0;
+    for (int f = 0; f < 6; ++f) {
+      const int d = f >> 1, s = f & 1;
+      if ((bp.weak_mask >> f & 1) && cc[d] == (s ? nc[d] - 1 : 0)) faces |= 1 << f;
+    }
+    ok = ok && (faces & ((1 << f0) - 1)) == 0;
+    if (!__builtin_amdgcn_readfirstlane(__ballot(ok) != 0)) continue; // (wave-uniform skip only: the two half-waves fence together)
+    const int ix = 2 * cx + a, iy = 2 * cy + b, iz = 2 * cz + c;
+    const bool con = constrained_u(prm, ix, iy, iz);
+    const long long gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
+    const long long gp = (cx + (a < 2 ? a : 1)) + (long long)prm.ndp[0] * ((cy + (b < 2 ? b : 1)) + (long long)prm.ndp[1] * (cz + (c < 2 ? c : 1)));
+    double accU[FUSED ? MAXSRC : 1][3], accP[FUSED ? MAXSRC : 1];
+#pragma unroll
+    for (int o = 0; o < (FUSED ? MAXSRC : 1); ++o) accU[o][0] = accU[o][1] = accU[o][2] = accP[o] = 0.0;
+    const int nsrc = bp.g ? 1 : (FUSED ? prm.nsrc : 1);
+    for (int src = 0; src < nsrc; ++src) {
+      if (!bp.g) { // gather (read_dof_values: constrained velocity entries read as 0)
+        const double *us = FUSED ? prm.us[src] : prm.u, *ps = FUSED ? prm.ps[src] : prm.p;
+        if (lane27)
+          for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = (ok && !con) ? us[comp * prm.Nu + gu] : 0.0;
+        if (pnode) X[81 + a + 2 * b + 4 * c] = (ok && ps) ? ps[gp] : 0.0;
+      }
+      double rU[3] = {0, 0, 0}, rP = 0.0;
+      for (int f = 0; f < 6; ++f) {
+        if (!__builtin_amdgcn_readfirstlane(__ballot(ok && (faces >> f & 1)) != 0)) continue;
+        const bool on = ok && (faces >> f & 1); // per half-wave
+        const int d = f >> 1, s = f & 1, t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+        const int q1 = t32 % 3, q2 = (t32 / 3) % 3;
+        // 1D tables of face point (q1, q2) / of any point q: value and derivative of node n along direction dir
+        auto tv = [&](int dir, int qa, int qb, int n) { return dir == d ? tE[s * 3 + n] : tS[(dir == t1 ? qa : qb) * 3 + n]; };
+        auto td = [&](int dir, int qa, int qb, int n) { return dir == d ? tED[s * 3 + n] : tD[(dir == t1 ? qa : qb) * 3 + n]; };
+        auto tp = [&](int dir, int qa, int qb, int n) { return dir == d ? tEP[s * 2 + n] : tP[(dir == t1 ? qa : qb) * 2 + n]; };
+        double Ji[3][3], nrm[3], JxW = 0.0;
+        if (on && t32 < 9) { // geometry of this lane's face point
+          double xi[3];
+          xi[d] = s; xi[t1] = tX[q1]; xi[t2] = tX[q2];
+          const double fx[2] = {1 - xi[0], xi[0]}, fy[2] = {1 - xi[1], xi[1]}, fz[2] = {1 - xi[2], xi[2]}, dd[2] = {-1.0, 1.0};
+          double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+          const long long nvx = prm.ncx + 1, nvy = prm.ncy + 1;
+          for (int k = 0; k < 2; ++k)
+            for (int j = 0; j < 2; ++j)
+              for (int i = 0; i < 2; ++i) {
+                const double *V = prm.vertices + 3 * ((cx + i) + nvx * ((cy + j) + nvy * (long long)(cz + k)));
+                for (int e = 0; e < 3; ++e) {
+                  const double Ve = V[e];
+                  J[e][0] += Ve * dd[i] * fy[j] * fz[k];
+                  J[e][1] += Ve * fx[i] * dd[j] * fz[k];
+                  J[e][2] += Ve * fx[i] * fy[j] * dd[k];
+                }
+              }
+          const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                             J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+          const double id = 1.0 / det;
+          Ji[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id;
+          Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+          Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+          Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) * id;
+          Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+          Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+          Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id;
+          Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+          Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+          double m[3], len = 0.0;
+          for (int k = 0; k < 3; ++k) {
+            m[k] = (s ? 1.0 : -1.0) * (d == 0 ? Ji[0][k] : (d == 1 ? Ji[1][k] : Ji[2][k]));
+            len += m[k] * m[k];
+          }
+          len = sqrt(len);
+          for (int k = 0; k < 3; ++k) nrm[k] = m[k] / len;
+          JxW = fabs(det) * len * tW[q1] * tW[q2];
+          sJ[slot][t32] = JxW;
+        }
+        wave_fence();
+        if (on && t32 < 9) {
+          double area = 0.0;
+          for (int q = 0; q < 9; ++q) area += sJ[slot][q];
+          const double h = sqrt(area); // get_h_face: area^(1 / (dim - 1))
+          double val[3], nd[3], pq;
+          if (bp.g) { // operators.h:1921-1932
+            const int c1 = cc[t1], c2 = cc[t2];
+            long long pt = 0;
+            for (int ff = 0; ff < f; ++ff)
+              if (bp.weak_mask >> ff & 1) pt += 9ll * (bp.foff[ff + 1] - bp.foff[ff]);
+            pt += 9ll * (c1 + (long long)nc[t1] * c2) + t32;
+            const double g0 = bp.g[3 * pt], g1 = bp.g[3 * pt + 1], g2 = bp.g[3 * pt + 2];
+            const double gq[3] = {g0, g1, g2};
+            const double gn = g0 * nrm[0] + g1 * nrm[1] + g2 * nrm[2];
+            for (int comp = 0; comp < 3; ++comp) {
+              val[comp] = ((bp.gamma1 / h) * gq[comp] + (bp.gamma2 / h) * nrm[comp] * gn) * JxW;
+              nd[comp] = -prm.nu * gq[comp] * JxW;
+            }
+            pq = -gn * JxW;
+          } else { // operators.h:1720-1739
+            double uval[3] = {0, 0, 0}, gref[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, pval = 0.0;
+            for (int kc = 0; kc < 3; ++kc)
+              for (int kb = 0; kb < 3; ++kb)
+                for (int ka = 0; ka < 3; ++ka) {
+                  const double sx = tv(0, q1, q2, ka), sy = tv(1, q1, q2, kb), sz = tv(2, q1, q2, kc);
+                  const double dx = td(0, q1, q2, ka) * sy * sz, dy = sx * td(1, q1, q2, kb) * sz, dz = sx * sy * td(2, q1, q2, kc);
+                  for (int comp = 0; comp < 3; ++comp) {
+                    const double w = X[comp * 27 + ka + 3 * kb + 9 * kc];
+                    gref[comp][0] += w * dx; gref[comp][1] += w * dy; gref[comp][2] += w * dz;
+                    uval[comp] += w * sx * sy * sz;
+                  }
+                }
+            for (int kc = 0; kc < 2; ++kc)
+              for (int kb = 0; kb < 2; ++kb)
+                for (int ka = 0; ka < 2; ++ka)
+                  pval += X[81 + ka + 2 * kb + 4 * kc] * tp(0, q1, q2, ka) * tp(1, q1, q2, kb) * tp(2, q1, q2, kc);
+            double un = 0.0, gn[3];
+            for (int comp = 0; comp < 3; ++comp) {
+              gn[comp] = 0.0;
+              for (int k = 0; k < 3; ++k)
+                gn[comp] += (gref[comp][0] * Ji[0][k] + gref[comp][1] * Ji[1][k] + gref[comp][2] * Ji[2][k]) * nrm[k];
+              un += uval[comp] * nrm[comp];
+            }
+            for (int comp = 0; comp < 3; ++comp) {
+              val[comp] = (-prm.nu * gn[comp] + pval * nrm[comp] + (bp.gamma1 / h) * uval[comp] + (bp.gamma2 / h) * nrm[comp] * un) * JxW;
+              nd[comp] = -prm.nu * uval[comp] * JxW;
+            }
+            pq = -un * JxW;
+          }
+          double *F = sF[slot][t32], *G = sG[slot][t32];
+          for (int comp = 0; comp < 3; ++comp) { F[comp] = val[comp]; F[3 + comp] = nd[comp]; }
+          F[6] = pq;
+          for (int e = 0; e < 3; ++e)
+            for (int k = 0; k < 3; ++k) G[3 * e + k] = Ji[e][k];
+          for (int k = 0; k < 3; ++k) G[9 + k] = nrm[k];
+        }
+        wave_fence();
+        if (on && lane27) { // integrate: test values and test normal derivatives of node (a, b, c)
+          for (int q = 0; q < 9; ++q) {
+            const int qa = q % 3, qb = q / 3;
+            const double *F = sF[slot][q], *G = sG[slot][q];
+            const double sx = tv(0, qa, qb, a), sy = tv(1, qa, qb, b), sz = tv(2, qa, qb, c);
+            const double gr[3] = {td(0, qa, qb, a) * sy * sz, sx * td(1, qa, qb, b) * sz, sx * sy * td(2, qa, qb, c)};
+            double dn = 0.0;
+            for (int k = 0; k < 3; ++k) dn += (gr[0] * G[k] + gr[1] * G[3 + k] + gr[2] * G[6 + k]) * G[9 + k];
+            const double v = sx * sy * sz;
+            for (int comp = 0; comp < 3; ++comp) rU[comp] += v * F[comp] + dn * F[3 + comp];
+            if (pnode) rP += tp(0, qa, qb, a) * tp(1, qa, qb, b) * tp(2, qa, qb, c) * F[6];
+          }
+        }
+        wave_fence(); // the next face reuses the point buffers
+      }
+      if (FUSED && !bp.g) {
+#pragma unroll
+        for (int o = 0; o < MAXSRC; ++o)
+          if (o < prm.nout) {
+            for (int comp = 0; comp < 3; ++comp) accU[o][comp] = fma(prm.fKu[o][src], rU[comp], accU[o][comp]);
+            accP[o] = fma(prm.fKp[o][src], rP, accP[o]);
+          }
+      } else {
+        for (int comp = 0; comp < 3; ++comp) accU[0][comp] = rU[comp];
+        accP[0] = rP;
+      }
+      wave_fence(); // the next source overwrites X
+    }
+    // distribute_local_to_global (add): constrained velocity rows are not written
+    if (ok && lane27) {
+      for (int o = 0; o < prm.nout; ++o) {
+        const double kU = (FUSED || bp.g) ? 1.0 : prm.wKu[o], kP = (FUSED || bp.g) ? 1.0 : prm.wKp[o];
+        const int oa = (FUSED && !bp.g) ? o : 0;
+        if (prm.out_u[o] && !con && kU != 0.0) {
+          double *dptr = prm.out_u[o] + gu;
+          for (int comp = 0; comp < 3; ++comp) dptr[comp * prm.Nu] += kU * accU[oa][comp];
+        }
+        if (pnode && prm.out_p[o] && kP != 0.0) prm.out_p[o][gp] += kP * accP[oa];
+      }
+    }
+  }
+}
+
 } // namespace
 
 struct stfem_stokes_ctx {
@@ -408,6 +631,13 @@ struct stfem_stokes_ctx {
   double *d_vertices = nullptr;
   int n_cu = 256;
   StokesParams base;
+  // weak (Nitsche) / outflow boundary faces (operators.h:1206-1211): bit f = 2 d + s
+  int weak_mask = 0, outflow_mask = 0;
+  double penalty1 = 20.0, penalty2 = 10.0;
+  BoundaryParams bnd;
+  double *d_g = nullptr; // Dirichlet data at the face quadrature points (stfem_stokes_nitsche_rhs)
+  size_t g_points = 0;
+  std::vector<double> h_vertices;
 };
 
 static thread_local char g_stokes_err[256] = "";
@@ -480,6 +710,8 @@ int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double
     delete c;
     return STFEM_ERR_HIP;
   }
+  c->h_vertices = v;
+  std::memset(&c->bnd, 0, sizeof(c->bnd));
   // 1D tables: FE_Q(2) and FE_Q(1) on Gauss-Lobatto nodes at the 3 Gauss points
   StokesParams &b = c->base;
   std::memset(&b, 0, sizeof(b));
@@ -515,6 +747,7 @@ void stfem_stokes_destroy(stfem_stokes_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_vertices) (void)hipFree(c->d_vertices);
+  if (c->d_g) (void)hipFree(c->d_g);
   delete c;
 }
 
@@ -561,6 +794,27 @@ int stfem_stokes_vector_download(stfem_stokes_ctx *c, int variable, const double
   return STFEM_OK;
 }
 
+static int stokes_boundary_launch(stfem_stokes_ctx *c, StokesParams &prm, const double *d_g, hipStream_t st)
+{
+  BoundaryParams bp = c->bnd;
+  bp.g = d_g;
+  const long long items = bp.foff[6];
+  if (items == 0) return STFEM_OK;
+  const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, 4ll * c->n_cu);
+  (void)hipGetLastError();
+  for (int colour = 0; colour < 8; ++colour) {
+    prm.colour = colour;
+    if (prm.nsrc > 1 && !d_g) hipLaunchKernelGGL(stokes_boundary_kernel<true>, dim3(grid), dim3(256), 0, st, prm, bp);
+    else hipLaunchKernelGGL(stokes_boundary_kernel<false>, dim3(grid), dim3(256), 0, st, prm, bp);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_stokes_err, sizeof(g_stokes_err), "stokes_boundary_kernel: %s", hipGetErrorString(e));
+    return STFEM_ERR_HIP;
+  }
+  return STFEM_OK;
+}
+
 static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
 {
   (void)hipGetLastError();
@@ -585,11 +839,19 @@ static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
     void *args[] = {(void *)&prm};
     (void)hipLaunchKernel(kern, dim3(grid), dim3(256), args, 0, st);
   }
-  const hipError_t e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_stokes_err, sizeof(g_stokes_err), "stokes_cell_kernel: %s", hipGetErrorString(e));
     return STFEM_ERR_HIP;
   }
+  // LoopType::Full: the boundary-face loop of the same vmult (the mass operator has none)
+  bool k_part = false;
+  if (prm.nsrc > 1) {
+    for (int o = 0; o < prm.nout; ++o)
+      for (int q = 0; q < prm.nsrc; ++q) k_part = k_part || prm.fKu[o][q] != 0.0 || prm.fKp[o][q] != 0.0;
+  } else
+    for (int o = 0; o < prm.nout; ++o) k_part = k_part || prm.wKu[o] != 0.0 || prm.wKp[o] != 0.0;
+  if (c->weak_mask && k_part) return stokes_boundary_launch(c, prm, nullptr, st);
   return STFEM_OK;
 }
 
@@ -763,6 +1025,97 @@ int stfem_stokes_st_vmult_slice_add(stfem_stokes_ctx *c, int n_timesteps_at_once
       }
     }
   return prm.nout ? stokes_launch(c, prm, st) : STFEM_OK;
+}
+
+// ---- weak boundary conditions (operators.h:1206-1211, 1220-1221; StokesNitscheMatrixFreeOperator 1768-1951) ----
+int stfem_stokes_set_weak_boundaries(stfem_stokes_ctx *c, int weak_mask, int outflow_mask, double penalty1, double penalty2)
+{
+  if (!c || weak_mask < 0 || weak_mask > 63 || outflow_mask < 0 || outflow_mask > 63) return STFEM_ERR_INVALID_ARGUMENT;
+  // a face in both sets takes the outflow branch in the reference (1680: checked first), i.e. no term in the linear operator
+  c->outflow_mask = outflow_mask;
+  c->weak_mask = weak_mask & ~outflow_mask;
+  c->penalty1 = penalty1;
+  c->penalty2 = penalty2;
+  BoundaryParams &b = c->bnd;
+  std::memset(&b, 0, sizeof(b));
+  b.weak_mask = c->weak_mask;
+  b.gamma1 = c->nu * penalty1;
+  b.gamma2 = penalty2;
+  int off = 0;
+  for (int f = 0; f < 6; ++f) {
+    b.foff[f] = off;
+    const int d = f / 2, t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+    if (c->weak_mask >> f & 1) off += c->nc[t1] * c->nc[t2];
+  }
+  b.foff[6] = off;
+  const stfem::ShapeTables tu = stfem::make_shape_tables(2), tp = stfem::make_shape_tables(1);
+  const std::vector<double> ends = {0.0, 1.0};
+  stfem::Mat Eu, EDu, Ep, EDp;
+  stfem::lagrange_tables(tu.nodes, ends, Eu, EDu);
+  stfem::lagrange_tables(tp.nodes, ends, Ep, EDp);
+  for (int i = 0; i < 6; ++i) { b.Eu[i] = Eu[i]; b.EDu[i] = EDu[i]; }
+  for (int i = 0; i < 4; ++i) b.Ep[i] = Ep[i];
+  return STFEM_OK;
+}
+
+int64_t stfem_stokes_n_face_points(const stfem_stokes_ctx *c) { return c ? 9ll * c->bnd.foff[6] : 0; }
+
+int stfem_stokes_face_points(const stfem_stokes_ctx *c, double *out)
+{
+  if (!c || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  std::vector<double> xq, wq;
+  stfem::gauss_rule(3, xq, wq);
+  const long long nvx = c->nc[0] + 1, nvy = c->nc[1] + 1;
+  size_t pt = 0;
+  for (int f = 0; f < 6; ++f) {
+    if (!(c->weak_mask >> f & 1)) continue;
+    const int d = f / 2, s = f % 2, t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+    for (int c2 = 0; c2 < c->nc[t2]; ++c2)
+      for (int c1 = 0; c1 < c->nc[t1]; ++c1) {
+        int cc[3];
+        cc[d] = s ? c->nc[d] - 1 : 0; cc[t1] = c1; cc[t2] = c2;
+        for (int q2 = 0; q2 < 3; ++q2)
+          for (int q1 = 0; q1 < 3; ++q1, ++pt) {
+            double xi[3];
+            xi[d] = s; xi[t1] = xq[q1]; xi[t2] = xq[q2];
+            double x[3] = {0, 0, 0};
+            for (int k = 0; k < 2; ++k)
+              for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < 2; ++i) {
+                  const double w = (i ? xi[0] : 1 - xi[0]) * (j ? xi[1] : 1 - xi[1]) * (k ? xi[2] : 1 - xi[2]);
+                  const double *V = c->h_vertices.data() + 3 * ((cc[0] + i) + nvx * ((cc[1] + j) + nvy * (long long)(cc[2] + k)));
+                  for (int e = 0; e < 3; ++e) x[e] += w * V[e];
+                }
+            for (int e = 0; e < 3; ++e) out[3 * pt + e] = x[e];
+          }
+      }
+  }
+  return STFEM_OK;
+}
+
+int stfem_stokes_nitsche_rhs(stfem_stokes_ctx *c, const double *g_at_face_points, double *dst_u, double *dst_p, void *stream)
+{
+  if (!c || !g_at_face_points || !dst_u || !dst_p) return STFEM_ERR_INVALID_ARGUMENT;
+  const size_t npts = size_t(stfem_stokes_n_face_points(c));
+  if (npts == 0) return STFEM_OK; // no Dirichlet functions: vmult does nothing (operators.h:1836)
+  STOKES_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c->g_points < npts) {
+    if (c->d_g) STOKES_TRY(hipFree(c->d_g));
+    c->d_g = nullptr;
+    c->g_points = 0;
+    if (hipMalloc(&c->d_g, npts * 3 * sizeof(double)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+    c->g_points = npts;
+  }
+  STOKES_TRY(hipMemcpyAsync(c->d_g, g_at_face_points, npts * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+  STOKES_TRY(hipStreamSynchronize(st)); // (the caller's host array may go away)
+  StokesParams prm = c->base;
+  prm.u = nullptr; prm.p = nullptr;
+  prm.nsrc = 0;
+  prm.nout = 1;
+  prm.out_u[0] = dst_u; prm.out_p[0] = dst_p;
+  prm.wKu[0] = prm.wKp[0] = 1.0;
+  return stokes_boundary_launch(c, prm, c->d_g, st);
 }
 
 } // extern "C"

@@ -123,7 +123,9 @@ struct PreconditionerGMGAdditionalData {
   double smoothing_range = 1;
   unsigned smoothing_degree = 5, smoothing_eig_cg_n_iterations = 20, smoothing_steps = 1;
   double relaxation = 0.0; // 0: estimated from the largest eigenvalue of P^-1 A (deal.II PreconditionRelaxation)
-  std::string coarse_grid_smoother_type = "Smoother";
+  std::string coarse_grid_smoother_type = "Smoother"; // anything else: GMRES on the coarsest level (stmg.h:1240-1308)
+  unsigned coarse_grid_maxiter = 10;                  // include/parameters.h:25-27
+  double coarse_grid_abstol = 1e-20, coarse_grid_reltol = 1e-4;
   SupportedSmoothers smoother = SupportedSmoothers::Relaxation;
   bool restrict_is_transpose_prolongate = true;
   bool variable = true;
@@ -448,7 +450,7 @@ public:
       mg_operators(mg_operators), precondition_vanka(mg_smoother_)
   {
     const unsigned n_levels = unsigned(mg_operators.size());
-    if (additional_data.coarse_grid_smoother_type != "Smoother") throw std::invalid_argument("GMG: only the smoother as coarse solver is built");
+    if (additional_data.coarse_grid_smoother_type != "Smoother") use_graph = false; // the coarse GMRES reads its inner products back every step
     std::vector<BlockSlice> blk_indices = get_blk_indices(type, n_timesteps_at_once, 1u, n_levels, mg_type_level, poly_time_sequence);
     // build_stmg_transfers (stmg.h:503-617)
     std::vector<std::shared_ptr<Context>> contexts(n_levels);
@@ -531,8 +533,9 @@ private:
   // Multigrid::level_v_step
   void level_v_step(unsigned level) const
   {
-    if (level == 0) { // MGCoarseGridApplySmoother
-      smooth(0, solution[0], defect[0], true);
+    if (level == 0) {
+      if (additional_data.coarse_grid_smoother_type != "Smoother") coarse_gmres(solution[0], defect[0]); // MGCoarseGridIterativeSolver
+      else smooth(0, solution[0], defect[0], true);                                                       // MGCoarseGridApplySmoother
       return;
     }
     smooth(level, solution[level], defect[level], true);
@@ -543,6 +546,59 @@ private:
     transfer_block->prolongate(level, t[level], solution[level - 1], stream_);
     axpby(1.0, t[level], 1.0, solution[level], stream_);
     smooth(level, solution[level], defect[level], false);
+  }
+  // The reference's coarse solver for coarseGridSmootherType != "Smoother" (stmg.h:1240-1308): SolverGMRES with
+  // IterationNumberControl(coarse_grid_maxiter, coarse_grid_abstol) and a basis of coarse_grid_maxiter vectors (no restart),
+  // left-preconditioned (deal.II's default) by the coarsest level's relaxation / Chebyshev preconditioner with
+  // smoothing_steps sweeps, started from zero (MGCoarseGridIterativeSolver sets dst = 0).  The residual that is
+  // controlled is the preconditioned one.
+  void coarse_gmres(BlockVectorType &x, const BlockVectorType &b) const
+  {
+    const unsigned m = std::max(1u, additional_data.coarse_grid_maxiter);
+    const double tol = additional_data.coarse_grid_abstol;
+    set_zero(x, stream_);
+    if (cv_.size() < m + 1) cv_.resize(m + 1);
+    for (auto &v : cv_)
+      if (!v.handle()) v.reinit(x.context(), x.n_blocks());
+    if (!cw_.handle()) cw_.reinit(x.context(), x.n_blocks());
+    if (precondition_sequence[0] == unsigned(SupportedSmoothers::Identity)) axpby(1.0, b, 0.0, cv_[0], stream_);
+    else mg_smoother[0].vmult(cv_[0], b, stream_);
+    const double beta = norm(cv_[0]);
+    if (!(beta > tol)) return;
+    axpby(0.0, cv_[0], 1.0 / beta, cv_[0], stream_);
+    std::vector<double> H(size_t(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1, 0.0), hcol(m);
+    g[0] = beta;
+    unsigned j = 0;
+    for (; j < m;) {
+      mg_operators[0]->vmult(cw_, cv_[j], stream_);
+      if (precondition_sequence[0] == unsigned(SupportedSmoothers::Identity)) axpby(1.0, cw_, 0.0, cv_[j + 1], stream_);
+      else mg_smoother[0].vmult(cv_[j + 1], cw_, stream_);
+      const double hn = orthogonalize(cv_, j + 1, cv_[j + 1], hcol.data());
+      for (unsigned i = 0; i <= j; ++i) H[i * m + j] = hcol[i];
+      H[(j + 1) * m + j] = hn;
+      if (hn > 0) axpby(0.0, cv_[j + 1], 1.0 / hn, cv_[j + 1], stream_);
+      for (unsigned i = 0; i < j; ++i) {
+        const double t1 = cs[i] * H[i * m + j] + sn[i] * H[(i + 1) * m + j];
+        H[(i + 1) * m + j] = -sn[i] * H[i * m + j] + cs[i] * H[(i + 1) * m + j];
+        H[i * m + j] = t1;
+      }
+      const double d = std::hypot(H[j * m + j], H[(j + 1) * m + j]);
+      cs[j] = H[j * m + j] / d;
+      sn[j] = H[(j + 1) * m + j] / d;
+      H[j * m + j] = d;
+      H[(j + 1) * m + j] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      ++j;
+      if (std::abs(g[j]) <= tol || !(hn > 0)) break;
+    }
+    std::vector<double> y(j);
+    for (int i = int(j) - 1; i >= 0; --i) {
+      double sum = g[i];
+      for (unsigned k = i + 1; k < j; ++k) sum -= H[i * m + k] * y[k];
+      y[i] = sum / H[i * m + i];
+    }
+    for (unsigned i = 0; i < j; ++i) axpby(y[i], cv_[i], 1.0, x, stream_);
   }
   // One cycle = a fixed sequence of ~10^3 launches on the level vectors this object owns.  With STFEM_MG_GRAPH=1 the first
   // call runs it as it is (the operators allocate their scratch on first use), the second records it into a hipGraph
@@ -600,6 +656,8 @@ private:
   std::unique_ptr<STMGTransferBlockMatrixFree<Number>> transfer_block;
   std::vector<PreconditionSTMG<Number, LevelMatrixType>> mg_smoother;
   mutable std::vector<BlockVectorType> defect, solution, t, d_;
+  mutable std::vector<BlockVectorType> cv_; // Krylov basis of the coarse GMRES
+  mutable BlockVectorType cw_;
   // the cycle's own stream (created on the first graph capture); the holder destroys it with the object,
   // after the graph (members are destroyed in reverse order of declaration)
   struct StreamHolder {

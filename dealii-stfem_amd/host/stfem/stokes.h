@@ -1,11 +1,15 @@
 // Host-side mirror of the reference's Stokes operators (include/operators.h:666-868
-// SystemMatrixStokes, 1193-1575 StokesMatrixFreeOperator; include/fe_time.h:901-1221 BlockSlice,
-// 1242-1285 get_fe_time_weights_stokes) on the C-ABI (stfem_stokes_*), cell loop only.
+// SystemMatrixStokes, 1193-1766 StokesMatrixFreeOperator, 1768-1951 StokesNitscheMatrixFreeOperator;
+// include/fe_time.h:901-1221 BlockSlice, 1242-1285 get_fe_time_weights_stokes) on the C-ABI (stfem_stokes_*):
+// cell loop and, for weak boundary ids, the boundary-face loop of the linear operator.
 #pragma once
 #include "fe_time.h"
 #include "operators.h"
 
 #include <array>
+#include <functional>
+#include <map>
+#include <set>
 
 namespace stfem {
 
@@ -105,14 +109,31 @@ private:
   size_t n_ = 0;
 };
 
-// operators.h:1193-1575 (cell loop; weak boundary ids / CIP faces are not built)
+// boundary ids of the structured block: 2 d + s (direction d, side s), as deal.II colorizes a hyper_rectangle
+using boundary_id = unsigned;
+
+// operators.h:1193-1766, linear operator: cell loop + boundary-face loop for the weak (Nitsche) ids.  Same constructor
+// arguments after the mesh as the reference (1199-1212); delta0 != 0 (CIP interior faces) and the nonlinear treatments throw.
 template <int dim, typename Number> class StokesMatrixFreeOperator {
   static_assert(dim == 3 && std::is_same<Number, double>::value, "3D, fp64");
 
 public:
   using BlockVectorType = std::vector<StokesVector>; // {velocity, pressure}
 
-  StokesMatrixFreeOperator(const Mesh &mesh, unsigned velocity_degree, Number viscosity)
+  StokesMatrixFreeOperator(const Mesh &mesh, unsigned velocity_degree, Number viscosity, const std::set<boundary_id> &weak_boundary_ids = {},
+                           const std::set<boundary_id> &outflow_boundary_ids = {}, Number penalty1 = 20, Number penalty2 = 10,
+                           Number /*outflow_penalty*/ = 0.0, Number delta0 = 0.0, Number /*delta1*/ = 0.0)
+  {
+    if (delta0 != 0.0) throw Error(STFEM_ERR_UNSUPPORTED, "StokesMatrixFreeOperator: the CIP face term (delta0 != 0) is not built");
+    create(mesh, velocity_degree, viscosity);
+    int weak = 0, outflow = 0;
+    for (boundary_id f : weak_boundary_ids) weak |= 1 << f;
+    for (boundary_id f : outflow_boundary_ids) outflow |= 1 << f;
+    if (weak || outflow) check(stfem_stokes_set_weak_boundaries(h_, weak, outflow, penalty1, penalty2), "stfem_stokes_set_weak_boundaries");
+  }
+
+private:
+  void create(const Mesh &mesh, unsigned velocity_degree, Number viscosity)
   {
     stfem_mesh_desc md{};
     for (int d = 0; d < 3; ++d) {
@@ -125,6 +146,8 @@ public:
     md.device = mesh.device;
     check(stfem_stokes_create(&md, int(velocity_degree), viscosity, &h_), "stfem_stokes_create");
   }
+
+public:
   ~StokesMatrixFreeOperator() { stfem_stokes_destroy(h_); }
   StokesMatrixFreeOperator(const StokesMatrixFreeOperator &) = delete;
 
@@ -151,6 +174,41 @@ public:
 
 private:
   stfem_stokes_ctx *h_ = nullptr;
+};
+
+// operators.h:1768-1951: the right-hand-side functional of the weakly imposed Dirichlet data.  It shares the geometry
+// of the StokesMatrixFreeOperator it is built from (the reference builds a second MatrixFree from the same arguments).
+template <int dim, typename Number> class StokesNitscheMatrixFreeOperator {
+public:
+  using BlockVectorType = std::vector<StokesVector>;
+  using Function = std::function<std::array<Number, 3>(const std::array<Number, 3> &)>; // Function<dim, Number>::vector_value
+
+  explicit StokesNitscheMatrixFreeOperator(const StokesMatrixFreeOperator<dim, Number> &op) : op_(op)
+  {
+    points_.resize(3 * size_t(stfem_stokes_n_face_points(op.handle())));
+    if (!points_.empty()) check(stfem_stokes_face_points(op.handle(), points_.data()), "stfem_stokes_face_points");
+  }
+  // operators.h:1801-1807.  One function for all weak faces here (the reference maps boundary ids to functions; the
+  // points of the faces come in ascending face order, so a caller with several functions can switch on the point)
+  void set_dirichlet_functions(const Function &g) const { g_ = g; }
+  void initialize_dof_vector(BlockVectorType &vec) const { op_.initialize_dof_vector(vec); }
+  // operators.h:1833-1849: dst += the boundary integrals of g; nothing without Dirichlet functions
+  void vmult(BlockVectorType &dst, void *stream = nullptr) const
+  {
+    if (!g_ || points_.empty()) return;
+    std::vector<Number> gq(points_.size());
+    for (size_t q = 0; q < points_.size() / 3; ++q) {
+      const auto v = g_({{points_[3 * q], points_[3 * q + 1], points_[3 * q + 2]}});
+      for (int e = 0; e < 3; ++e) gq[3 * q + e] = v[e];
+    }
+    check(stfem_stokes_nitsche_rhs(op_.handle(), gq.data(), dst.at(0).data(), dst.at(1).data(), stream), "StokesNitscheMatrixFreeOperator::vmult");
+  }
+  unsigned long long m() const { return op_.m(); }
+
+private:
+  const StokesMatrixFreeOperator<dim, Number> &op_;
+  std::vector<double> points_;
+  mutable Function g_;
 };
 
 // operators.h:666-868; blocks in BlockSlice order

@@ -27,6 +27,31 @@ template <typename Number> void set_zero(BlockVectorT<Number> &v, void *stream =
 }
 template <typename Number> double norm(const BlockVectorT<Number> &x) { return std::sqrt(dot(x, x)); }
 
+// The Gram-Schmidt step of the Krylov solvers: w is orthogonalised against v_0 .. v_{k-1}, h[i] receives the
+// coefficients, the return value is ||w|| afterwards.  One rank: the re-orthogonalised classical scheme on the device
+// (stfem_orthogonalize twice: a handful of launches and two read-backs whatever k is; deal.II's SolverGMRES uses a
+// classical scheme with delayed re-orthogonalisation for the same reason).  Partitioned vectors: the modified scheme
+// with one reducing inner product per vector (stfem_dot_global), as before.
+template <typename Number> double orthogonalize(const std::vector<BlockVectorT<Number>> &vs, unsigned k, BlockVectorT<Number> &w, double *h)
+{
+  const Context &c = *w.context();
+  if (c.comm || w.n_blocks() > 8 || k > 240) {
+    for (unsigned i = 0; i < k; ++i) {
+      h[i] = dot(w, vs[i]);
+      axpby(-h[i], vs[i], 1.0, w);
+    }
+    return norm(w);
+  }
+  std::vector<const stfem_vec *> handles(k);
+  for (unsigned i = 0; i < k; ++i) handles[i] = vs[i].handle();
+  std::vector<double> h2(k);
+  double n2 = 0.0;
+  check(stfem_orthogonalize(c.h, int(k), handles.data(), w.handle(), 0, h, nullptr, nullptr), "stfem_orthogonalize");
+  check(stfem_orthogonalize(c.h, int(k), handles.data(), w.handle(), 0, h2.data(), &n2, nullptr), "stfem_orthogonalize");
+  for (unsigned i = 0; i < k; ++i) h[i] += h2[i];
+  return std::sqrt(std::max(n2, 0.0));
+}
+
 // One block of a block vector as a one-block vector of its own (a view: nothing is copied)
 template <typename Number> BlockVectorT<Number> block_view(const BlockVectorT<Number> &v, unsigned b)
 {
@@ -144,12 +169,9 @@ public:
         fresh(vs[j + 1]);
         P.vmult(zs[j], vs[j]);
         A.vmult(vs[j + 1], zs[j]);
-        for (unsigned i = 0; i <= j; ++i) {
-          const double h = dot(vs[j + 1], vs[i]);
-          H[i * m + j] = h;
-          axpby(-h, vs[i], 1.0, vs[j + 1]);
-        }
-        const double hn = norm(vs[j + 1]);
+        hcol.resize(j + 1);
+        const double hn = orthogonalize(vs, j + 1, vs[j + 1], hcol.data());
+        for (unsigned i = 0; i <= j; ++i) H[i * m + j] = hcol[i];
         H[(j + 1) * m + j] = hn;
         if (hn > 0) axpby(1.0 / hn, vs[j + 1], 0.0, vs[j + 1]);
         for (unsigned i = 0; i < j; ++i) {
@@ -190,6 +212,7 @@ private:
   unsigned restart, steps = 0;
   double value = 0.0;
   std::vector<V> vs, zs;
+  std::vector<double> hcol;
 };
 
 // The temporal basis: Lagrange polynomials through get_time_quad's points (fe_time.cc:152-169), evaluated at x

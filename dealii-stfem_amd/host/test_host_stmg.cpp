@@ -1,7 +1,7 @@
 // One V-cycle of the space-time multigrid mirror (host/stfem/stmg.h) on a small mesh, written out for the comparison with
 // the numpy restatement (tests/test_gpu_stmg.py): levels as tests/tp_01.cc:170-200 derives them.
 // Usage: test_host_stmg <type 0 = cG | 1 = dG> <k> <cells per direction> <n_timesteps_at_once> <fe_degree> <coarsening 0 = space_or_time |
-//                       1 = space_and_time> <pmg 0|1> <double|float> <distort> <out.bin> [relaxation = 0 (estimated)] [variable = 1] [smoother 1 = relaxation | 2 = Chebyshev] [smoothing steps = 1]
+//                       1 = space_and_time> <pmg 0|1> <double|float> <distort> <out.bin> [relaxation = 0 (estimated)] [variable = 1] [smoother 1 = relaxation | 2 = Chebyshev] [smoothing steps = 1] [coarse GMRES iterations = 0 (the smoother)]
 // out.bin: uint64 {n_levels, n_blocks, n_dofs}, double relaxation[n_levels], smoother id[n_levels], src[n_blocks][n_dofs], dst[n_blocks][n_dofs]
 #include "stfem/stmg.h"
 
@@ -33,6 +33,10 @@ template <typename NP> int run(int argc, char **argv)
   if (argc > 12) mg_data.variable = std::atoi(argv[12]) != 0;
   if (argc > 13 && std::atoi(argv[13]) == 2) mg_data.smoother = SupportedSmoothers::Chebyshev; // then "relaxation" in the output is the eigenvalue estimate
   if (argc > 14) mg_data.smoothing_steps = std::atoi(argv[14]);
+  if (argc > 15 && std::atoi(argv[15]) > 0) { // coarseGridSmootherType != "Smoother": GMRES on the coarsest level (stmg.h:1240-1308)
+    mg_data.coarse_grid_smoother_type = "Solver";
+    mg_data.coarse_grid_maxiter = std::atoi(argv[15]);
+  }
   STMGHierarchy<3, NP> mg(mesh, fe_degree, poly_space, type, tau, nsteps, mg_type_level, poly_time, mg_data, ctype, false, true);
   std::printf("levels:");
   for (auto m : mg_type_level) std::printf(" %c", char(m));

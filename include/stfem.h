@@ -151,6 +151,17 @@ int stfem_tensorproduct_add(stfem_ctx *ctx, int nrows, int ncols, const double *
                             const stfem_vec *b, void *stream);
 int stfem_dot(stfem_ctx *ctx, const stfem_vec *a, const stfem_vec *b, int64_t n_own, double *out,
               void *stream);
+/* The Gram-Schmidt step of the Krylov solvers (SolverFGMRES / SolverGMRES of deal.II: k inner products and k vector updates per
+ * iteration) in a few launches and ONE read-back.  All reductions are two-stage with a fixed summation order: bitwise reproducible.
+ *   multi_dot:     out[i] = <a_i, b>, i < k (host array; synchronous)
+ *   multi_axpy:    y += sum_i coef_i x_i (coefficients from the host; asynchronous)
+ *   orthogonalize: one classical Gram-Schmidt pass h = V^T w, w -= V h with the coefficients kept on the device, then
+ *                  h_out[0 .. k) <- h and, if norm2_out is given, <w, w> after the projection (synchronous).  Twice in a row it
+ *                  is the re-orthogonalised classical scheme (as stable as the modified one, k times fewer launches and waits). */
+int stfem_multi_dot(stfem_ctx *ctx, int k, const stfem_vec *const *a, const stfem_vec *b, int64_t n_own, double *out, void *stream);
+int stfem_multi_axpy(stfem_ctx *ctx, int k, const double *coef, const stfem_vec *const *x, stfem_vec *y, void *stream);
+int stfem_orthogonalize(stfem_ctx *ctx, int k, const stfem_vec *const *v, stfem_vec *w, int64_t n_own, double *h_out, double *norm2_out,
+                        void *stream);
 
 /* Halo support for z-slab partitions (deal.II: update_ghost_values / compress(add) inside
  * MatrixFree::cell_loop, operators.h:1016-1017).  A rank's top DoF plane (iz = nz-1) is the
@@ -391,6 +402,24 @@ int stfem_stokes_st_vmult_slice_add(stfem_stokes_ctx *ctx, int n_timesteps_at_on
                                     int variable_major, const double *Gamma, const double *Zeta,
                                     double *const *dst_blocks, const double *src_u,
                                     const double *src_p, void *stream);
+/* Weak boundary conditions of StokesMatrixFreeOperator (reference include/operators.h:1206-1211, 1220-1221, 1640-1741) and
+ * StokesNitscheMatrixFreeOperator (1768-1951), linear operator (NonlinearTreatment::None).
+ * Faces are numbered f = 2 d + s (direction d, side s: 0 = lower, 1 = upper; bit f of the masks) - the boundary ids of deal.II's
+ * colorized hyper_rectangle, the same bits as stfem_mesh_desc.dirichlet_mask (strong constraints; keep the sets disjoint).
+ *   set_weak_boundaries: faces in weak_mask get the Nitsche terms (gamma1 = viscosity penalty1, gamma2 = penalty2, h = sqrt(face
+ *       area)) in every later stfem_stokes_vmult / st_vmult / st_vmult_slice_add (LoopType::Full); faces in outflow_mask add
+ *       nothing to the linear operator (the reference's back-flow term carries a factor 0.0, the rest is nonlinear-only) and
+ *       take precedence over weak_mask, as the reference checks them first (operators.h:1680).
+ *   n_face_points / face_points: the quadrature points of the weak faces, out[point][3] (host), in the order faces ascending /
+ *       cells of a face lexicographic with the lower tangential axis fastest / q = q1 + 3 q2 - where the Dirichlet function is
+ *       evaluated (velocity.quadrature_point(q), operators.h:1911-1914).
+ *   nitsche_rhs: StokesNitscheMatrixFreeOperator::vmult(dst): the boundary functional of the Dirichlet data g (host array
+ *       [point][3] in that order) is ADDED to dst_u / dst_p (device).  Synchronises `stream` once (upload of g).
+ * Not built: the CIP interior-face term (delta0 != 0, operators.h:1603-1638) and the convection modes (form / jacobian). */
+int stfem_stokes_set_weak_boundaries(stfem_stokes_ctx *ctx, int weak_mask, int outflow_mask, double penalty1, double penalty2);
+int64_t stfem_stokes_n_face_points(const stfem_stokes_ctx *ctx);
+int stfem_stokes_face_points(const stfem_stokes_ctx *ctx, double *out);
+int stfem_stokes_nitsche_rhs(stfem_stokes_ctx *ctx, const double *g_at_face_points, double *dst_u, double *dst_p, void *stream);
 const char *stfem_stokes_last_hip_error(void);
 
 const char *stfem_strerror(int status);

@@ -64,6 +64,13 @@ def lib():
         L.stfo_stokes_n_pressure.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.stfo_stokes_apply.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
+        L.stfo_stokes_n_face_points.restype = C.c_long
+        L.stfo_stokes_n_face_points.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.stfo_stokes_face_points.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, _dp]
+        L.stfo_stokes_boundary_apply.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                 C.c_double, _dp, _dp, _dp, _dp]
+        L.stfo_stokes_nitsche_rhs.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                              _dp, _dp, _dp]
         L.stfb_st_vmult.argtypes = [C.c_int, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.c_int, _dp, _dp,
                                     C.POINTER(_dp), C.POINTER(_dp), _dp, C.c_int]
         # default thread count: the visible CPUs, but never more than 16 (a GPU box advertises 256
@@ -222,10 +229,12 @@ class StokesOracle:
     the reference's structure (operators.h:825-867: K.vmult, scatter with Alpha, M.vmult, scatter
     with Beta, one source time dof after the other)."""
 
-    def __init__(self, ncell, vertices, dirichlet_mask, viscosity, pu=2):
+    def __init__(self, ncell, vertices, dirichlet_mask, viscosity, pu=2, weak_mask=0, penalty1=20.0, penalty2=10.0):
         self.nc = (C.c_int * 3)(*ncell)
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1)
         self.mask, self.nu, self.pu = int(dirichlet_mask), float(viscosity), pu
+        # weak (Nitsche) boundary faces, operators.h:1206-1211, 1220-1221: gamma1 = nu penalty1, gamma2 = penalty2
+        self.weak, self.penalty1, self.penalty2 = int(weak_mask), float(penalty1), float(penalty2)
         self.n_u = lib().stfo_stokes_n_velocity(self.nc, pu)
         self.n_p = lib().stfo_stokes_n_pressure(self.nc, pu)
 
@@ -236,6 +245,24 @@ class StokesOracle:
         rc = lib().stfo_stokes_apply(self.nc, _p(self.vertices), self.pu, self.mask, self.nu, wK, wM,
                                      _p(U), _p(P), _p(ou), _p(op), 0)
         assert rc == 0
+        if self.weak and wK != 0.0:  # LoopType::Full: the boundary-face loop of the same vmult
+            rc = lib().stfo_stokes_boundary_apply(self.nc, _p(self.vertices), self.pu, self.mask, self.weak, self.nu, self.penalty1,
+                                                  self.penalty2, wK, _p(U), _p(P), _p(ou), _p(op))
+            assert rc == 0
+        return ou.reshape(3, self.n_u), op
+
+    def face_points(self):
+        n = lib().stfo_stokes_n_face_points(self.nc, self.pu, self.weak)
+        out = np.zeros((n, 3))
+        assert lib().stfo_stokes_face_points(self.nc, _p(self.vertices), self.pu, self.weak, _p(out)) == 0
+        return out
+
+    def nitsche_rhs(self, g_at_face_points):
+        """StokesNitscheMatrixFreeOperator::vmult (operators.h:1833-1849, 1898-1940) for the Dirichlet data at face_points()"""
+        g = np.ascontiguousarray(g_at_face_points, dtype=np.float64)
+        ou = np.zeros(3 * self.n_u); op = np.zeros(self.n_p)
+        assert lib().stfo_stokes_nitsche_rhs(self.nc, _p(self.vertices), self.pu, self.mask, self.weak, self.nu, self.penalty1,
+                                             self.penalty2, _p(g), _p(ou), _p(op)) == 0
         return ou.reshape(3, self.n_u), op
 
     def st_vmult(self, Alpha, Beta, n_timesteps, n_timedofs, blocks, variable_major=True):

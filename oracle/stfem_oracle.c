@@ -139,6 +139,19 @@ void stfo_shape_tables(int p, int nq, double *S, double *D)
     }
 }
 
+/* the same tables at arbitrary points of [0, 1] (face evaluation: the end points 0 and 1) */
+void stfo_shape_tables_at(int p, int npts, const double *pts, double *S, double *D)
+{
+  double xi[MAXN];
+  const int n1 = p + 1;
+  stfo_gauss_lobatto(n1, xi);
+  for (int q = 0; q < npts; ++q)
+    for (int a = 0; a < n1; ++a) {
+      S[q * n1 + a] = lagrange(n1, xi, a, pts[q]);
+      D[q * n1 + a] = lagrange_deriv(n1, xi, a, pts[q]);
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* spatial operator                                                           */
 /* ------------------------------------------------------------------------- */

@@ -99,6 +99,20 @@ int stfo_stokes_apply(const int ncell[3], const double *vertices, int pu, int di
                       double nu, double wK, double wM, const double *u, const double *p,
                       double *out_u, double *out_p, int add);
 
+/* Boundary faces of the linear Stokes operator (operators.h:1640-1741, 1898-1940).  Face f = 2 d + s (bit f of weak_mask):
+ * direction d, side s - the boundary ids of deal.II's colorized hyper_rectangle.  Face quadrature points in the order
+ * faces ascending / cells of a face lexicographic, lower tangential axis fastest / q = q1 + nq q2.
+ *   boundary_apply: the Nitsche terms of the weak faces, times wK, ADDED to out_u / out_p
+ *   nitsche_rhs:    StokesNitscheMatrixFreeOperator::vmult for Dirichlet data g given at the face points, ADDED */
+void stfo_shape_tables_at(int p, int npts, const double *pts, double *S, double *D);
+long stfo_stokes_n_face_points(const int ncell[3], int pu, int weak_mask);
+int stfo_stokes_face_points(const int ncell[3], const double *vertices, int pu, int weak_mask, double *out_xyz);
+int stfo_stokes_boundary_apply(const int ncell[3], const double *vertices, int pu, int dirichlet_mask, int weak_mask, double nu,
+                               double penalty1, double penalty2, double wK, const double *u, const double *p, double *out_u,
+                               double *out_p);
+int stfo_stokes_nitsche_rhs(const int ncell[3], const double *vertices, int pu, int dirichlet_mask, int weak_mask, double nu,
+                            double penalty1, double penalty2, const double *g_at_face_points, double *out_u, double *out_p);
+
 #ifdef __cplusplus
 }
 #endif

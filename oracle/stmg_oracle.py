@@ -176,8 +176,35 @@ class Multigrid:
     None for the identity, omega, n_iterations); transfers[l] = (P, R) between level l - 1 and l (matrices acting on the
     flattened block vectors)."""
 
-    def __init__(self, levels, transfers, variable=True, steps=1):
+    def __init__(self, levels, transfers, variable=True, steps=1, coarse_gmres=None):
+        """coarse_gmres = (maxiter, abstol): the reference's coarseGridSmootherType != "Smoother" (stmg.h:1240-1308):
+        MGCoarseGridIterativeSolver around SolverGMRES(IterationNumberControl(maxiter, abstol), basis maxiter), left-preconditioned
+        by the coarsest level's relaxation preconditioner, from the zero vector."""
         self.levels, self.transfers, self.variable, self.steps = levels, transfers, variable, steps
+        self.coarse_gmres = coarse_gmres
+
+    def _coarse_gmres(self, b):
+        """The GMRES iterate in its defining form: x_k minimises || P^-1 (b - A x) || over the Krylov space
+        K_k(P^-1 A, P^-1 b) (dense least squares on an orthonormalised basis, no Arnoldi recurrence), k = the first step at
+        which the preconditioned residual is below abstol, else maxiter."""
+        maxiter, abstol = self.coarse_gmres
+        A = self.levels[0]["A"]
+        M = lambda v: self._precondition(0, v)  # noqa: E731
+        r0 = M(b)
+        if np.linalg.norm(r0) <= abstol:
+            return np.zeros_like(b)
+        K = [r0 / np.linalg.norm(r0)]
+        x = np.zeros_like(b)
+        for k in range(1, maxiter + 1):
+            Q, _ = np.linalg.qr(np.stack(K, axis=1))
+            MAQ = np.stack([M(A @ Q[:, i]) for i in range(Q.shape[1])], axis=1)
+            y, *_ = np.linalg.lstsq(MAQ, r0, rcond=None)
+            x = Q @ y
+            if np.linalg.norm(r0 - MAQ @ y) <= abstol or k == maxiter:
+                break
+            w = M(A @ K[-1])
+            K.append(w / np.linalg.norm(w))
+        return x
 
     def _precondition(self, l, r):
         lv = self.levels[l]
@@ -212,7 +239,7 @@ class Multigrid:
 
     def _v(self, l, defect):
         if l == 0:
-            return self._smooth(0, None, defect, True)
+            return self._coarse_gmres(defect) if self.coarse_gmres else self._smooth(0, None, defect, True)
         u = self._smooth(l, None, defect, True)
         t = defect - self.levels[l]["A"] @ u
         P, R = self.transfers[l]

@@ -93,6 +93,108 @@ def dense_stokes(pu, ncell, vertices, mask):
     return K, M, B
 
 
+def face_tables(p, pts):
+    """values / reference gradients of the 3D Lagrange basis at the tensor points pts[2] x pts[1] x pts[0] (x fastest)"""
+    nodes = gll01_np(p + 1)
+    VG = [lagrange_table(nodes, np.asarray(pt, dtype=float)) for pt in pts]
+    (Vx, Gx), (Vy, Gy), (Vz, Gz) = VG
+    n1 = p + 1
+    nq = len(pts[0]) * len(pts[1]) * len(pts[2])
+    N = np.einsum("zc,yb,xa->zyxcba", Vz, Vy, Vx).reshape(nq, n1 ** 3)
+    dN = np.stack([np.einsum("zc,yb,xa->zyxcba", Vz, Vy, Gx).reshape(nq, n1 ** 3),
+                   np.einsum("zc,yb,xa->zyxcba", Vz, Gy, Vx).reshape(nq, n1 ** 3),
+                   np.einsum("zc,yb,xa->zyxcba", Gz, Vy, Vx).reshape(nq, n1 ** 3)], axis=1)
+    return N, dN
+
+
+def dense_nitsche(pu, ncell, vertices, mask, weak, nu, penalty1, penalty2, gfun):
+    """Weak (Nitsche) boundary faces of the linear Stokes operator, reference include/operators.h:1713-1741:
+         a_F((u,p),(v,q)) = int_F  -nu (grad u n).v + p n.v + gamma1/h u.v + gamma2/h (u.n)(v.n) - nu u.(grad v n) - q u.n
+       with gamma1 = nu penalty1, gamma2 = penalty2, h = sqrt(area of the face)  (operators.h:184-209, 1220-1221)
+       and the functional of StokesNitscheMatrixFreeOperator (operators.h:1898-1940) for the Dirichlet data gfun(x).
+       Returns Auu [3 NU, 3 NU], Aup [3 NU, NP], Apu [NP, 3 NU], Fu [3 NU], Fp [NP], face points, g at them."""
+    pp, nq = pu - 1, pu + 1
+    xq, wq = gauss01(nq)
+    ndu = [pu * n + 1 for n in ncell]; ndp = [pp * n + 1 for n in ncell]
+    NU, NP = int(np.prod(ndu)), int(np.prod(ndp))
+    Auu = np.zeros((3 * NU, 3 * NU)); Aup = np.zeros((3 * NU, NP)); Apu = np.zeros((NP, 3 * NU))
+    Fu = np.zeros(3 * NU); Fp = np.zeros(NP)
+    g1, g2 = nu * penalty1, penalty2
+    nvx, nvy = ncell[0] + 1, ncell[1] + 1
+    verts = vertices.reshape(-1, 3)
+    all_pts, all_g = [], []
+    for f in range(6):
+        if not weak & (1 << f):
+            continue
+        d, sd = f // 2, f % 2
+        t1, t2 = [e for e in range(3) if e != d]
+        pts = [None] * 3
+        pts[d] = [float(sd)]; pts[t1] = xq; pts[t2] = xq
+        Nu_, dNu = face_tables(pu, pts)
+        Np_, _ = face_tables(pp, pts)
+        Wf = np.einsum("b,a->ba", wq, wq).reshape(-1)  # q = q1 + nq q2 (the point tables run x fastest: t1 < t2)
+        grid = np.meshgrid(*[np.asarray(pts[2]), np.asarray(pts[1]), np.asarray(pts[0])], indexing="ij")
+        QZ, QY, QX = [gq.reshape(-1) for gq in grid]
+        for c2 in range(ncell[t2]):
+            for c1 in range(ncell[t1]):
+                cc = [0, 0, 0]
+                cc[d] = ncell[d] - 1 if sd else 0; cc[t1] = c1; cc[t2] = c2
+                cx, cy, cz = cc
+                X = np.array([verts[(cx + i) + nvx * ((cy + j) + nvy * (cz + k))] for k in range(2) for j in range(2) for i in range(2)])
+                fx = np.stack([1 - QX, QX], 1); fy = np.stack([1 - QY, QY], 1); fz = np.stack([1 - QZ, QZ], 1)
+                dd = np.array([-1.0, 1.0])
+                nqf = len(QX)
+                J = np.zeros((nqf, 3, 3)); xyz = np.zeros((nqf, 3))
+                for k in range(2):
+                    for j in range(2):
+                        for i in range(2):
+                            Xv = X[i + 2 * j + 4 * k]
+                            J[:, :, 0] += np.outer(dd[i] * fy[:, j] * fz[:, k], Xv)
+                            J[:, :, 1] += np.outer(fx[:, i] * dd[j] * fz[:, k], Xv)
+                            J[:, :, 2] += np.outer(fx[:, i] * fy[:, j] * dd[k], Xv)
+                            xyz += np.outer(fx[:, i] * fy[:, j] * fz[:, k], Xv)
+                det = np.linalg.det(J); Jinv = np.linalg.inv(J)
+                m = (1.0 if sd else -1.0) * Jinv[:, d, :]
+                ln = np.linalg.norm(m, axis=1)
+                n = m / ln[:, None]
+                JxW = np.abs(det) * ln * Wf
+                h = np.sqrt(JxW.sum())
+                gph = np.einsum("qed,qea->qda", Jinv, dNu)       # physical gradients of the velocity shape functions
+                dn = np.einsum("qda,qd->qa", gph, n)             # their normal derivatives
+                gq = np.array([gfun(x) for x in xyz])
+                all_pts.append(xyz); all_g.append(gq)
+                nun = (pu + 1) ** 3
+                iu = np.array([(pu * cx + a) + ndu[0] * ((pu * cy + b) + ndu[1] * (pu * cz + c))
+                               for c in range(pu + 1) for b in range(pu + 1) for a in range(pu + 1)])
+                ip = np.array([(pp * cx + a) + ndp[0] * ((pp * cy + b) + ndp[1] * (pp * cz + c))
+                               for c in range(pp + 1) for b in range(pp + 1) for a in range(pp + 1)])
+                NN = np.einsum("q,qa,qb->ab", JxW, Nu_, Nu_)
+                NdN = np.einsum("q,qa,qb->ab", JxW, Nu_, dn)     # v-value x normal derivative of u
+                for c in range(3):
+                    rows = c * NU + iu
+                    Auu[np.ix_(rows, rows)] += -nu * NdN + (g1 / h) * NN - nu * NdN.T
+                    for c2_ in range(3):
+                        cols = c2_ * NU + iu
+                        Auu[np.ix_(rows, cols)] += (g2 / h) * np.einsum("q,qa,qb->ab", JxW * n[:, c] * n[:, c2_], Nu_, Nu_)
+                    Aup[np.ix_(rows, ip)] += np.einsum("q,qa,qb->ab", JxW * n[:, c], Nu_, Np_)
+                    Apu[np.ix_(ip, rows)] += -np.einsum("q,qb,qa->ba", JxW * n[:, c], Np_, Nu_)
+                    gn = np.einsum("qd,qd->q", gq, n)
+                    Fu[rows] += np.einsum("q,qa->a", JxW * ((g1 / h) * gq[:, c] + (g2 / h) * n[:, c] * gn), Nu_) \
+                        - nu * np.einsum("q,qa->a", JxW * gq[:, c], dn)
+                Fp[ip] += -np.einsum("q,qb->b", JxW * np.einsum("qd,qd->q", gq, n), Np_)
+                del nun
+    con = np.zeros(ndu[::-1], dtype=bool)
+    if mask & 1: con[:, :, 0] = True
+    if mask & 2: con[:, :, -1] = True
+    if mask & 4: con[:, 0, :] = True
+    if mask & 8: con[:, -1, :] = True
+    if mask & 16: con[0, :, :] = True
+    if mask & 32: con[-1, :, :] = True
+    con3 = np.tile(con.reshape(-1), 3)
+    Auu[con3, :] = 0; Auu[:, con3] = 0; Aup[con3, :] = 0; Apu[:, con3] = 0; Fu[con3] = 0
+    return Auu, Aup, Apu, Fu, Fp, np.concatenate(all_pts), np.concatenate(all_g)
+
+
 def stokes_apply(K, M, B, nu, U, P):
     """U [3, NU], P [NP] -> (nu K u - B^T p, B u, M u)"""
     ou = np.stack([nu * K @ U[c] - B[c].T @ P for c in range(3)])
@@ -148,5 +250,35 @@ def main():
               "B*1", np.abs(sum(B[c] @ np.ones(NU) for c in range(3))).max() if mask == 0 else "-")
 
 
+def main_nitsche():
+    """weak-boundary fixtures: StokesMatrixFreeOperator::vmult with Nitsche faces (LoopType::Full) and
+    StokesNitscheMatrixFreeOperator::vmult for a smooth Dirichlet function"""
+    gfun = lambda x: np.array([np.sin(1.3 * x[0] + 0.4 * x[1]) + x[2], np.cos(0.7 * x[1] - x[2]) * x[0], 0.5 + x[0] * x[1] - 0.3 * x[2] ** 2])  # noqa: E731
+    cases = [
+        # name, ncell, lower, upper, jitter, strong mask, weak mask, nu, penalty1, penalty2
+        ("stokes_nitsche_cart_2x2x2", (2, 2, 2), (0, 0, 0), (1, 1.5, 0.7), 0.0, 0b001100, 0b110011, 1.0, 20.0, 10.0),
+        ("stokes_nitsche_pert_2x3x2", (2, 3, 2), (0, 0, 0), (1, 1, 1), 0.15, 0, 0b111111, 0.05, 20.0, 10.0),
+        ("stokes_nitsche_pert_3x2x2", (3, 2, 2), (-1, -1, -1), (1, 1, 1), 0.1, 0b010000, 0b100110, 2.5, 15.0, 4.0),
+    ]
+    for (name, ncell, lo, up, jit, mask, weak, nu, pen1, pen2) in cases:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        verts = structured_vertices(ncell, lo, up, jit, seed=29)
+        K, M, B = dense_stokes(2, ncell, verts, mask)
+        Auu, Aup, Apu, Fu, Fp, pts, gq = dense_nitsche(2, ncell, verts, mask, weak, nu, pen1, pen2, gfun)
+        NU, NP = K.shape[0], B.shape[1]
+        U = rng.uniform(-1, 1, size=(3, NU)); P = rng.uniform(-1, 1, size=NP)
+        ou, op, _ = stokes_apply(K, M, B, nu, U, P)
+        SU = ou + (Auu @ U.reshape(-1) + Aup @ P).reshape(3, NU)
+        SP = op + Apu @ U.reshape(-1)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), ncell=np.array(ncell), vertices=verts, mask=mask, weak=weak, nu=nu,
+                            penalty1=pen1, penalty2=pen2, U=U, P=P, SU=SU, SP=SP, FU=Fu.reshape(3, NU), FP=Fp, face_points=pts, G=gq)
+        print(name, "NU", NU, "NP", NP, "face points", len(pts), "|Auu|", np.abs(Auu).max(), "sym", np.abs(Auu - Auu.T).max(),
+              "Aup + Apu^T", np.abs(Aup + Apu.T).max())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "nitsche":
+        main_nitsche()
+    else:
+        main()
+        main_nitsche()

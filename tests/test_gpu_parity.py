@@ -299,6 +299,37 @@ def test_blas1_and_planes(stfem):
     assert abs(stfem.dot(ctx, b, b, n_own=n - plane) - np.sum(X[:, :n - plane] ** 2)) < 1e-10
 
 
+@pytest.mark.parametrize("number", ["double", "float"])
+def test_gram_schmidt_step_on_the_device(number, stfem):
+    """stfem_multi_dot / stfem_multi_axpy / stfem_orthogonalize (the Gram-Schmidt step of SolverFGMRES / SolverGMRES): against
+    numpy, and bitwise reproducible (two-stage reductions with a fixed order; stfem_dot too)"""
+    ctx = stfem.MatrixFreeOperator(2, (9, 7, 5), number=number)
+    nb, k = 3, 11
+    rng = np.random.default_rng(2)
+    f = (lambda a: a.astype(np.float32).astype(np.float64)) if number == "float" else (lambda a: a)
+    V = [f(rng.uniform(-1, 1, (nb, ctx.n_dofs))) for _ in range(k)]
+    W = f(rng.uniform(-1, 1, (nb, ctx.n_dofs)))
+    vs = [stfem.BlockVector(ctx, nb).upload(v) for v in V]
+    w = stfem.BlockVector(ctx, nb).upload(W)
+    tol = 1e-13 if number == "double" else 1e-6
+    want = np.array([np.sum(v * W) for v in V])
+    got = stfem.multi_dot(ctx, vs, w)
+    assert np.allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
+    assert np.array_equal(got, stfem.multi_dot(ctx, vs, w))
+    d1 = stfem.dot(ctx, vs[0], w)
+    assert d1 == stfem.dot(ctx, vs[0], w) and d1 == got[0]
+    coef = rng.uniform(-1, 1, k)
+    stfem.multi_axpy(ctx, coef, vs, w)
+    W2 = w.download()
+    assert rel(W2, W + sum(c * v for c, v in zip(coef, V))) < (1e-14 if number == "double" else 1e-6)
+    h, n2 = stfem.orthogonalize(ctx, vs, w)
+    hw = np.array([np.sum(v * W2) for v in V])
+    assert np.allclose(h, hw, rtol=tol, atol=tol * np.abs(hw).max())
+    W3 = W2 - sum(c * v for c, v in zip(h, V))
+    assert rel(w.download(), W3) < (1e-13 if number == "double" else 2e-6)
+    assert abs(n2 - np.sum(w.download() ** 2)) <= (1e-12 if number == "double" else 1e-5) * n2
+
+
 @pytest.mark.parametrize("name", CART_FIXTURES + GENERAL_FIXTURES)
 def test_diagonal(name, stfem, golden_dir):
     """compute_diagonal (operators.h:1092-1110): forward diagonal of K and of M."""

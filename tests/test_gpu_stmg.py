@@ -78,7 +78,7 @@ def test_vector_convert():
     assert np.array_equal(vc.download(), X.astype(np.float32).astype(float))
 
 
-def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distort, omegas, ids, variable=True, steps=1):
+def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distort, omegas, ids, variable=True, steps=1, coarse_gmres=None):
     """the hierarchy of host/test_host_stmg.cpp rebuilt from the restatement"""
     from oracle import stmg_oracle, vanka_oracle
     tau = 0.0625
@@ -131,7 +131,7 @@ def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distor
             Pt, Rt = stmg_oracle.time_transfer(ttype, kind, struct[l][0], struct[l - 1][0], struct[l][1])
             N = levels[l]["N"]
             transfers.append((sp.kron(Pt, sp.eye(N)).tocsr(), sp.kron(Rt, sp.eye(N)).tocsr()))
-    return seq, levels, stmg_oracle.Multigrid(levels, transfers, variable=variable)
+    return seq, levels, stmg_oracle.Multigrid(levels, transfers, variable=variable, coarse_gmres=coarse_gmres)
 
 
 @pytest.mark.parametrize("number", ["double", "float"])
@@ -190,6 +190,29 @@ def test_vcycle_chebyshev_vs_oracle(number, tmp_path, oracle_mod):
         want = stmg_oracle.power_iteration(lv["A"], lv["smoother"], lv["nb"], lv["N"])
         assert abs(lambdas[l] - want) < (1e-8 if number == "double" else 2e-3) * want
     assert rel(dst, mg.vmult(src)) < (1e-9 if number == "double" else 5e-3)
+
+
+@pytest.mark.parametrize("number", ["double", "float"])
+@pytest.mark.parametrize("ttype,k,n,nsteps,p,maxiter", [(0, 2, 6, 1, 2, 10), (1, 1, 6, 2, 1, 4)])  # 6 -> 3 cells per direction: a coarsest level with interior DoFs
+def test_vcycle_gmres_coarse_solver_vs_oracle(ttype, k, n, nsteps, p, maxiter, number, tmp_path, oracle_mod):
+    """the reference's other coarse solver (coarseGridSmootherType = Solver, stmg.h:1240-1308): `maxiter` steps of left-preconditioned
+    GMRES on the coarsest level, against the least-squares definition of the GMRES iterate"""
+    from oracle import stmg_oracle
+    stfem = importlib.import_module("dealii-stfem_amd")
+    exe = os.path.join(HOST, "test_host_stmg")
+    out = tmp_path / "stmg.bin"
+    res = subprocess.run([exe, str(ttype), str(k), str(n), str(nsteps), str(p), "0", "0", number, "0.0", str(out), "0", "1", "1", "1", str(maxiter)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    n_levels, nb, N = (int(x) for x in np.fromfile(out, dtype=np.uint64, count=3))
+    flat = np.fromfile(out, dtype=np.float64, offset=24)
+    omegas, ids = flat[:n_levels], flat[n_levels:2 * n_levels].astype(int)
+    src, dst = flat[2 * n_levels:].reshape(2, nb * N)
+    seq, levels, mg = _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, "space_or_time", False, 0.0, omegas, ids, coarse_gmres=(maxiter, 1e-20))
+    assert rel(dst, mg.vmult(src)) < (1e-8 if number == "double" else 5e-3)
+    plain = stmg_oracle.Multigrid(mg.levels, mg.transfers, variable=True).vmult(src)
+    # the coarse solver is visible in this cycle far above the fp64 tolerance of the comparison (3e-6 / 2e-4 of the result)
+    assert rel(plain, mg.vmult(src)) > 1e-6
 
 
 @pytest.mark.parametrize("ttype,k,refinement,nsteps,extra", [

@@ -167,3 +167,84 @@ def test_stokes_axis_aligned_mesh_vs_oracle(nc, upper, mask, stfem):
         op.st_vmult(Alpha, Beta, 1, nt, dst, src, True)
         for j in range(2 * nt):
             assert np.linalg.norm(dst[j].download() - ref[j]) <= TOL * np.linalg.norm(ref[j]) + 1e-14, (plane, j)
+
+
+# ---- weak (Nitsche) boundary faces: StokesMatrixFreeOperator with weak_boundary_ids (LoopType::Full) and
+# StokesNitscheMatrixFreeOperator (reference include/operators.h:1640-1741, 1768-1951)
+NITSCHE_FIXTURES = ["stokes_nitsche_cart_2x2x2", "stokes_nitsche_pert_2x3x2", "stokes_nitsche_pert_3x2x2"]
+
+
+def _ids(mask):
+    return [f for f in range(6) if mask >> f & 1]
+
+
+@pytest.mark.parametrize("name", NITSCHE_FIXTURES)
+def test_stokes_nitsche_golden_fixture(name, stfem):
+    """the dense numpy assembly of the face terms (tests/golden/make_golden_stokes.py: full 3D shape tables at the face points)"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    op = stfem.StokesMatrixFreeOperator(tuple(g["ncell"]), vertices=g["vertices"], dirichlet_mask=int(g["mask"]), viscosity=float(g["nu"]),
+                                        weak_boundary_ids=_ids(int(g["weak"])), penalty1=float(g["penalty1"]), penalty2=float(g["penalty2"]))
+    u, p = op.initialize_dof_vector(0, g["U"]), op.initialize_dof_vector(1, g["P"])
+    ou, opr = op.initialize_dof_vector(0, np.full(3 * op.n_velocity, 7.0)), op.initialize_dof_vector(1, np.full(op.n_pressure, -3.0))
+    op.vmult(ou, opr, u, p)
+    assert rel(ou.download(), g["SU"]) < TOL and rel(opr.download(), g["SP"]) < TOL
+    # the right-hand-side functional of the Dirichlet data
+    assert np.abs(op.face_points() - g["face_points"]).max() < 1e-14
+    fu, fp = op.initialize_dof_vector(0), op.initialize_dof_vector(1)
+    op.nitsche_rhs(g["G"], fu, fp)
+    assert rel(fu.download(), g["FU"]) < TOL and rel(fp.download(), g["FP"]) < TOL
+    op.nitsche_rhs(g["G"], fu, fp)  # accumulates (distribute_local_to_global)
+    assert rel(fu.download(), 2 * g["FU"]) < TOL and rel(fp.download(), 2 * g["FP"]) < TOL
+
+
+@pytest.mark.parametrize("nc,distort,mask,weak,outflow", [
+    ((5, 4, 6), 0.15, 0, 0b111111, 0),             # every face weak: edge and corner cells carry two and three faces
+    ((6, 5, 4), 0.1, 0b110000, 0b001011, 0b000100),  # strong z faces, weak x and upper-y faces, outflow at y = 0 (no term)
+    ((3, 3, 3), 0.0, 0b000001, 0b101010, 0),       # axis-aligned cells given by vertices
+])
+def test_stokes_nitsche_vs_oracle(nc, distort, mask, weak, outflow, stfem):
+    """operator with weak faces, space-time scatter (fused and unfused launches) and vmult_slice_add against the CPU oracle"""
+    from oracle import oracle
+    nu, pen1, pen2 = 0.3, 20.0, 10.0
+    verts = stfem.mesh_vertices(nc, distort=distort, seed=41) if distort else stfem.mesh_vertices(nc)
+    op = stfem.StokesMatrixFreeOperator(nc, vertices=verts, dirichlet_mask=mask, viscosity=nu, weak_boundary_ids=_ids(weak),
+                                        outflow_boundary_ids=_ids(outflow), penalty1=pen1, penalty2=pen2)
+    orc = oracle.StokesOracle(nc, verts, mask, nu, weak_mask=weak & ~outflow, penalty1=pen1, penalty2=pen2)
+    rng = np.random.default_rng(9)
+    U, Pp = rng.uniform(-1, 1, 3 * orc.n_u), rng.uniform(-1, 1, orc.n_p)
+    ku, kp = orc.apply(U, Pp)
+    u, p = op.initialize_dof_vector(0, U), op.initialize_dof_vector(1, Pp)
+    ou, opr = op.initialize_dof_vector(0), op.initialize_dof_vector(1)
+    op.vmult(ou, opr, u, p)
+    assert rel(ou.download(), ku) < TOL and rel(opr.download(), kp) < TOL
+    first = (ou.download(), opr.download())
+    op.vmult(ou, opr, u, p)  # colour launches, plain read-add-write: reproducible to the bit
+    assert np.array_equal(ou.download(), first[0]) and np.array_equal(opr.download(), first[1])
+    # the vector mass has no face term
+    mu, _ = orc.apply(U, Pp, 0.0, 1.0)
+    m = op.initialize_dof_vector(0)
+    op.mass_vmult(m, u)
+    assert rel(m.download(), mu) < TOL
+    for ns, r in ((1, 2), (2, 3)):  # 2 time dofs: one fused set of launches; 6: one launch set per source
+        Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 16, ns)
+        nt, nb = r, 2 * r * ns
+        blocks = [None] * nb
+        for it in range(ns):
+            for d in range(nt):
+                blocks[stfem.stokes_block_index(nt, it, 0, d)] = rng.uniform(-1, 1, 3 * orc.n_u)
+                blocks[stfem.stokes_block_index(nt, it, 1, d)] = rng.uniform(-1, 1, orc.n_p)
+        ref = orc.st_vmult(Alpha, Beta, ns, nt, blocks, True)
+        var = [0 if b.size == 3 * orc.n_u else 1 for b in blocks]
+        src = [op.initialize_dof_vector(v, b) for v, b in zip(var, blocks)]
+        dst = [op.initialize_dof_vector(v, np.full(b.size, 11.0)) for v, b in zip(var, blocks)]
+        op.st_vmult(Alpha, Beta, ns, nt, dst, src, True)
+        for j in range(nb):
+            assert rel(dst[j].download(), ref[j]) < TOL, (ns, r, j)
+    # Dirichlet data functional against the oracle at the oracle's own face points
+    pts = orc.face_points()
+    assert np.abs(op.face_points() - pts).max() < 1e-13
+    G = np.stack([np.sin(pts[:, 0] + 2 * pts[:, 1]), pts[:, 2] ** 2 - pts[:, 0], np.cos(pts[:, 1] * pts[:, 2])], axis=1)
+    fu, fp = op.initialize_dof_vector(0), op.initialize_dof_vector(1)
+    op.nitsche_rhs(G, fu, fp)
+    ru, rp = orc.nitsche_rhs(G)
+    assert rel(fu.download(), ru) < TOL and rel(fp.download(), rp) < TOL

@@ -72,17 +72,18 @@ def test_cpp_caller_matches_oracle(case, number, tmp_path, oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [((3, 2, 4), 0, 2, 1, 0.5), ((2, 3, 2), 1, 1, 2, 2.0)])
+@pytest.mark.parametrize("case", [((3, 2, 4), 0, 2, 1, 0.5, 0), ((2, 3, 2), 1, 1, 2, 2.0, 0), ((3, 3, 2), 0, 2, 1, 0.4, 0b100011)])
 def test_cpp_stokes_caller_matches_oracle(case, tmp_path):
-    """SystemMatrixStokes / StokesMatrixFreeOperator mirror (host/stfem/stokes.h) vs the CPU oracle."""
+    """SystemMatrixStokes / StokesMatrixFreeOperator / StokesNitscheMatrixFreeOperator mirror (host/stfem/stokes.h) vs the CPU oracle;
+    the last case with weak (Nitsche) boundary ids 0, 1, 5."""
     from oracle import oracle
-    nc, ttype, r, ns, nu = case
+    nc, ttype, r, ns, nu, weak = case
     stfem = importlib.import_module("dealii-stfem_amd")
     exe = os.path.join(HOST, "test_host_stokes")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     out = tmp_path / "stokes.bin"
-    res = subprocess.run([exe, *map(str, nc), str(ttype), str(r), str(ns), str(nu), str(out)],
+    res = subprocess.run([exe, *map(str, nc), str(ttype), str(r), str(ns), str(nu), str(out)] + ([str(weak)] if weak else []),
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     raw = np.fromfile(out, dtype=np.uint8)
@@ -96,9 +97,16 @@ def test_cpp_stokes_caller_matches_oracle(case, tmp_path):
         n = X[b].size
         Y.append(raw[off:off + 8 * n].view(np.float64).copy()); off += 8 * n
     verts = stfem.mesh_vertices(nc, distort=0.1, seed=99)
-    orc = oracle.StokesOracle(nc, verts, 63, nu)
+    orc = oracle.StokesOracle(nc, verts, 63 & ~weak, nu, weak_mask=weak)
     Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(ttype, r, 1.0 / 32, ns)
     nt = r if ttype == 0 else r + 1
     ref = orc.st_vmult(Alpha, Beta, ns, nt, X)
     for b in range(nb):
         assert np.linalg.norm(Y[b] - ref[b]) <= 1e-12 * np.linalg.norm(ref[b]), b
+    if weak:
+        FU = raw[off:off + 8 * 3 * orc.n_u].view(np.float64); off += 8 * 3 * orc.n_u
+        FP = raw[off:off + 8 * orc.n_p].view(np.float64)
+        pts = orc.face_points()
+        G = np.stack([np.sin(pts[:, 0] + 2 * pts[:, 1]), pts[:, 2] ** 2 - pts[:, 0], np.cos(pts[:, 1] * pts[:, 2])], axis=1)
+        ru, rp = orc.nitsche_rhs(G)
+        assert np.linalg.norm(FU - ru.reshape(-1)) <= 1e-12 * np.linalg.norm(ru) and np.linalg.norm(FP - rp) <= 1e-12 * np.linalg.norm(rp)

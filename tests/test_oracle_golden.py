@@ -118,3 +118,18 @@ def test_coefficient_function(oracle_mod):
     # first table entry (coarse cell 0,0,0) = first draw of mt19937(5489): 3499211612 / 2^32
     first = 0.5 + 3499211612 / 4294967296.0
     assert abs(f[0, 0] - first) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["stokes_nitsche_cart_2x2x2", "stokes_nitsche_pert_2x3x2", "stokes_nitsche_pert_3x2x2"])
+def test_stokes_oracle_nitsche_faces_vs_dense_fixture(name, oracle_mod, golden_dir):
+    """the boundary-face loop of the Stokes oracle (weak Nitsche faces, operators.h:1713-1741, and the functional of
+    StokesNitscheMatrixFreeOperator, 1898-1940) against the independent dense numpy assembly"""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    o = oracle_mod.StokesOracle(tuple(g["ncell"]), g["vertices"], int(g["mask"]), float(g["nu"]), weak_mask=int(g["weak"]),
+                                penalty1=float(g["penalty1"]), penalty2=float(g["penalty2"]))
+    ou, op = o.apply(g["U"], g["P"])
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(ou, g["SU"]) < 1e-13 and rel(op, g["SP"]) < 1e-13
+    assert np.abs(o.face_points() - g["face_points"]).max() < 1e-14
+    fu, fp = o.nitsche_rhs(g["G"])
+    assert rel(fu, g["FU"]) < 1e-13 and rel(fp, g["FP"]) < 1e-13
