@@ -76,6 +76,8 @@ SIGNATURES = {
     "stfem_diagonal": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
     "stfem_tensorproduct_add": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp]),
     "stfem_dot": (C.c_int, [_vp, _vp, _vp, C.c_int64, _dp, _vp]),
+    "stfem_trace_push": (None, [C.c_char_p]),
+    "stfem_trace_pop": (None, []),
     "stfem_multi_dot": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _vp]),
     "stfem_multi_axpy": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_vp), _vp, _vp]),
     "stfem_orthogonalize": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _dp, _vp]),

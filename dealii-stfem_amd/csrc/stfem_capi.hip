@@ -6,6 +6,7 @@
 #include "stfem_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -728,11 +729,53 @@ static int apply_tiled(stfem_ctx *c, int nbo, int nbi, const std::vector<double>
                  : apply_tiled_t<Prec64>(c, nbo, nbi, a, b, dst, src, add, use_lap_coef, use_mass_coef, stream);
 }
 
+// ---- named trace ranges (roctx): the reference's TimerOutput scopes "vmult" / "Tvmult" (operators.h:539, 564, 590), "vanka"
+// (stmg.h:835), "gmg" (stmg.h:1335, 1352) show up under the same names in `rocprofv3 --marker-trace`.  The roctx library of
+// the profiler SDK is bound at run time; without it the calls do nothing.
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+};
+const Roctx &roctx()
+{
+  static Roctx r = [] {
+    Roctx q;
+    if (const char *e = getenv("STFEM_TRACE"))
+      if (atoi(e) == 0) return q;
+    void *h = nullptr;
+    for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) return q;
+    q.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+    q.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!q.push || !q.pop) q.push = nullptr, q.pop = nullptr;
+    return q;
+  }();
+  return r;
+}
+} // namespace
+struct TraceScope {
+  explicit TraceScope(const char *name) { stfem_trace_push(name); }
+  ~TraceScope() { stfem_trace_pop(); }
+};
+void stfem_trace_push(const char *name)
+{
+  if (roctx().push) (void)roctx().push(name ? name : "stfem");
+}
+void stfem_trace_pop(void)
+{
+  if (roctx().pop) (void)roctx().pop();
+}
+
 int stfem_st_vmult(stfem_ctx *c, int nrows, int ncols, const double *alpha, const double *beta,
                    int transpose, int add, stfem_vec *dst, const stfem_vec *src, void *stream)
 {
   if (!c || !alpha || !beta || !dst || !src || nrows < 1 || ncols < 1)
     return STFEM_ERR_INVALID_ARGUMENT;
+  TraceScope scope(transpose ? "Tvmult" : "vmult");
   if (dst->ctx != c || src->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
   const int nbi = transpose ? nrows : ncols, nbo = transpose ? ncols : nrows;
   if (src->nb != nbi || dst->nb != nbo) return STFEM_ERR_SHAPE_MISMATCH;

@@ -1032,6 +1032,10 @@ int stfem_vanka_plan(const stfem_vanka *v, int32_t out[2])
 int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream)
 {
   if (!v || !dst || !src) return STFEM_ERR_INVALID_ARGUMENT;
+  struct Scope { // the reference's TimerOutput scope "vanka" (stmg.h:835)
+    Scope() { stfem_trace_push("vanka"); }
+    ~Scope() { stfem_trace_pop(); }
+  } scope;
   if (dst->ctx != v->ctx || src->ctx != v->ctx || dst->nb != v->nb || src->nb != v->nb) return STFEM_ERR_SHAPE_MISMATCH;
   for (int i = 0; i < v->nb; ++i)
     for (int j = 0; j < v->nb; ++j)

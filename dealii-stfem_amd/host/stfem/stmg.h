@@ -608,6 +608,7 @@ private:
   // their own dependent-load chains, the launches already overlap them.
   template <typename Number2> void cycle(BlockVectorT<Number2> &dst, const BlockVectorT<Number2> &src) const
   {
+    TraceRange scope("gmg"); // stmg.h:1335, 1352
     if (!stream_ && use_graph) check(stfem_stream_create(&stream_.s), "stfem_stream_create");
     transfer_block->copy_to_mg(defect, src, stream_);
     const unsigned n_levels = transfer_block->n_levels();

@@ -296,6 +296,7 @@ public:
   // solve (time_integrators.h:300-321); prev_x: one block
   void solve(V &x, const V &prev_x, V &rhs, double time, double time_step)
   {
+    TraceRange scope("step");
     const auto t0 = std::chrono::steady_clock::now();
     rhs_matrix.vmult_slice(rhs, prev_x);
     assemble_force(rhs, time, time_step);
@@ -364,6 +365,7 @@ public:
   // prev_u, prev_v: one block each
   void solve(V &u, V &v, V &rhs, const V &prev_u, const V &prev_v, double time, double time_step)
   {
+    TraceRange scope("step");
     const auto t0 = std::chrono::steady_clock::now();
     this->rhs_matrix.vmult_slice(rhs, prev_u);
     for (unsigned b = 0; b < u.n_blocks(); ++b) {

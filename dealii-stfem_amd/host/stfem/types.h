@@ -15,6 +15,15 @@
 
 namespace stfem {
 
+// a named trace range for the time of a scope (roctx through the C-ABI): the reference's TimerOutput::Scope
+struct TraceRange {
+  explicit TraceRange(const char *name) { stfem_trace_push(name); }
+  ~TraceRange() { stfem_trace_pop(); }
+  TraceRange(const TraceRange &) = delete;
+  TraceRange &operator=(const TraceRange &) = delete;
+};
+
+
 struct Error : std::runtime_error {
   int status;
   Error(int s, const std::string &what)

@@ -425,6 +425,11 @@ const char *stfem_stokes_last_hip_error(void);
 const char *stfem_strerror(int status);
 /* text of the last failing HIP call on this thread ("" if none) */
 const char *stfem_last_hip_error(void);
+/* Named trace ranges (roctx, bound at run time: no-ops without the profiler's library or with STFEM_TRACE=0).  The library
+ * opens "vmult" / "Tvmult" around stfem_st_vmult and "vanka" around stfem_vanka_vmult - the names of the reference's
+ * TimerOutput scopes (operators.h:539, 564, 590; stmg.h:835); callers add their own ("gmg", stmg.h:1335; "step"). */
+void stfem_trace_push(const char *name);
+void stfem_trace_pop(void);
 /* name of the kernel variant the last stfem_st_vmult on this ctx dispatched to (for profiles) */
 const char *stfem_last_kernel_name(const stfem_ctx *ctx);
 

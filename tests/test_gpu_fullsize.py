@@ -142,3 +142,54 @@ def test_cfg1_mesh_space_transfers_properties(stfem):
                 T.prolongate(pu, one_c)
                 assert np.abs(pu.download() - 1.0).max() < 1e-13
             del T, uc, vf, pu, rv, ipu, fine, coarse
+
+
+def test_cfg2_full_mesh_properties(stfem):
+    """BASELINE configs[2] at its REAL size on one GPU: 144^3 cells perturbed by 0.15 h, Q4 x cG(2), 384 M space-time DoFs
+    (the mesh bench.py --gpus N cuts into z-slabs).  All arithmetic of the checks runs on the device (stfem_vector_axpby,
+    stfem_dot): linearity, symmetry of K and of M, constrained rows exactly zero, K.1 = 0 on the unconstrained mesh."""
+    p, nc = 4, (144, 144, 144)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 1.0 / 288, 1)
+    verts = stfem.mesh_vertices(nc, distort=0.15)
+    ctx = stfem.MatrixFreeOperator(p, nc, vertices=verts)
+    n, nd = ctx.n_dofs, 4 * 144 + 1
+    assert 2 * n == 384200066 and not ctx.is_cartesian
+    L = stfem.lib()
+
+    def axpby(a, x, b, y):
+        assert L.stfem_vector_axpby(ctx._h, a, x._h, b, y._h, None) == 0
+
+    def constrained_space(seed):  # a random vector with zero boundary rows
+        t = np.random.default_rng(seed).uniform(-1, 1, (2, nd, nd, nd))
+        t[:, 0] = 0; t[:, -1] = 0; t[:, :, 0] = 0; t[:, :, -1] = 0; t[:, :, :, 0] = 0; t[:, :, :, -1] = 0
+        return stfem.BlockVector(ctx, 2).upload(t.reshape(2, n))
+
+    X, Y = constrained_space(7), constrained_space(8)
+    AX, AY, AZ, Z = (stfem.BlockVector(ctx, 2) for _ in range(4))
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    A.vmult(AX, X)
+    A.vmult(AY, Y)
+    assert ctx.last_kernel_name.startswith("st_")
+    axpby(1.0, X, 0.0, Z)
+    axpby(-2.0, Y, 1.0, Z)     # Z = X - 2 Y
+    A.vmult(AZ, Z)
+    axpby(-1.0, AX, 1.0, AZ)
+    axpby(2.0, AY, 1.0, AZ)    # A Z - A X + 2 A Y
+    assert stfem.dot(ctx, AZ, AZ) < 1e-26 * stfem.dot(ctx, AX, AX)
+    g = AX.download().reshape(2, nd, nd, nd)
+    assert np.all(g[:, 0] == 0.0) and np.all(g[:, :, :, -1] == 0.0) and np.all(g[:, :, 0] == 0.0) and np.abs(g).max() > 0
+    del g
+    I2, Z2 = np.eye(2), np.zeros((2, 2))
+    for (a, b) in ((I2, Z2), (Z2, I2)):  # K and M are symmetric
+        S = stfem.SystemMatrix(ctx, a, b)
+        S.vmult(AX, X)
+        S.vmult(AY, Y)
+        yx, xy = stfem.dot(ctx, Y, AX), stfem.dot(ctx, X, AY)
+        assert abs(yx - xy) < 1e-11 * abs(yx), (yx, xy)
+    del ctx, A, S, X, Y, AX, AY, AZ, Z
+    # K annihilates constants on the unconstrained mesh
+    free = stfem.MatrixFreeOperator(p, nc, vertices=verts, dirichlet_mask=0)
+    ones = stfem.BlockVector(free, 2).upload(np.ones((2, n)))
+    out = stfem.BlockVector(free, 2)
+    stfem.SystemMatrix(free, I2, Z2).vmult(out, ones)
+    assert np.abs(out.download()).max() < 1e-9
