@@ -133,6 +133,7 @@ SIGNATURES = {
     "stfem_graph_destroy": (None, [_vp]),
     "stfem_vanka_create": (C.c_int, [_vp, C.c_int, _dp, _dp, C.POINTER(_vp)]),
     "stfem_vanka_create_partitioned": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.POINTER(_vp)]),
+    "stfem_vanka_create_partitioned_general": (C.c_int, [_vp, _vp, C.c_int, _dp, _dp, C.c_int, C.POINTER(_vp)]),
     "stfem_vanka_destroy": (None, [_vp]),
     "stfem_vanka_n_classes": (C.c_int, [_vp]),
     "stfem_vanka_plan": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
@@ -403,15 +404,20 @@ class MatrixFreeOperator:
 class PreconditionVanka:
     """stmg.h:619-907: cell-patch additive-Schwarz smoother of Alpha (x) K + Beta (x) M on one context."""
 
-    def __init__(self, ctx, Alpha, Beta, neighbour_mask=0):
-        """neighbour_mask: faces (bits as dirichlet_mask) behind which another rank holds the next cells"""
+    def __init__(self, ctx, Alpha, Beta, neighbour_mask=0, extended=None):
+        """neighbour_mask: faces (bits as dirichlet_mask) behind which another rank holds the next cells; extended: on general
+        meshes the context of the slab plus one ghost cell layer per such face (stfem_vanka_create_partitioned_general)"""
         self.ctx = ctx
         A = np.ascontiguousarray(Alpha, dtype=np.float64)
         B = np.ascontiguousarray(Beta, dtype=np.float64)
         assert A.shape == B.shape and A.shape[0] == A.shape[1]
         h = _vp()
-        _check(lib().stfem_vanka_create_partitioned(ctx._h, A.shape[0], _p(A), _p(B), neighbour_mask, C.byref(h)),
-               "stfem_vanka_create")
+        if extended is not None:
+            _check(lib().stfem_vanka_create_partitioned_general(ctx._h, extended._h, A.shape[0], _p(A), _p(B), neighbour_mask, C.byref(h)),
+                   "stfem_vanka_create_partitioned_general")
+        else:
+            _check(lib().stfem_vanka_create_partitioned(ctx._h, A.shape[0], _p(A), _p(B), neighbour_mask, C.byref(h)),
+                   "stfem_vanka_create")
         self._h, self.n_blocks = h, A.shape[0]
 
     def __del__(self):

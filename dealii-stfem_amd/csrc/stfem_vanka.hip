@@ -483,6 +483,7 @@ struct stfem_vanka {
   stfem_ctx *ctx = nullptr;
   int nb = 0, nloc = 0, m = 0, mt = 0, mtw = 0, parts = 0, mpad = 0, kpad = 0, nclasses = 0;
   void *d_blocks = nullptr;
+  void *d_blocks_base = nullptr; // allocation d_blocks points into (blocks built on an extended context: the ghost layers' come first)
   int *d_off = nullptr;
   int *d_cell[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int *d_cls[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1008,11 +1009,65 @@ int stfem_vanka_create_partitioned(stfem_ctx *c, int nb, const double *Alpha, co
   return STFEM_OK;
 }
 
+// One block per cell on a z-slab of a partitioned GENERAL mesh (perturbed cells, coefficient tables: BASELINE configs[2] on more
+// than one rank).  The block of a cell next to the interface needs the cell matrices of the neighbour rank's cells
+// (stmg.h:688-689, 795-796 and compute_block_matrix.h:68-73: the reference builds the blocks on locally owned AND ghost cells):
+// the caller hands over a second context, `extended`, of the same slab plus one ghost cell layer on every side that has a
+// neighbour (the vertices of those layers are all that crosses the ranks, once).  The blocks are built on it as on any mesh and
+// the ones of the slab's own cells are kept; the apply runs on the slab and leaves PARTIAL sums in the interface planes like
+// the uniform-mesh variant (stfem_vanka_create_partitioned).
+int stfem_vanka_create_partitioned_general(stfem_ctx *slab, stfem_ctx *extended, int nb, const double *Alpha, const double *Beta,
+                                           int neighbour_mask, stfem_vanka **out)
+{
+  if (!slab || !extended || !Alpha || !Beta || !out || nb < 1) return STFEM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (neighbour_mask & ~(16 | 32)) return STFEM_ERR_UNSUPPORTED; // z-slabs
+  const int glo = (neighbour_mask & 16) ? 1 : 0, ghi = (neighbour_mask & 32) ? 1 : 0;
+  if (extended->p != slab->p || extended->prec != slab->prec || extended->device != slab->device || extended->nc[0] != slab->nc[0] ||
+      extended->nc[1] != slab->nc[1] || extended->nc[2] != slab->nc[2] + glo + ghi)
+    return STFEM_ERR_SHAPE_MISMATCH;
+  // the extended context carries the domain's constraints: none on a z face with a ghost layer, the slab's elsewhere
+  if ((extended->dmask & 15) != (slab->dmask & 15) || (glo && (extended->dmask & 16)) || (ghi && (extended->dmask & 32)) ||
+      (!glo && (extended->dmask & 16) != (slab->dmask & 16)) || (!ghi && (extended->dmask & 32) != (slab->dmask & 32)))
+    return STFEM_ERR_INVALID_ARGUMENT;
+  stfem_vanka *ve = nullptr;
+  int rc = stfem_vanka_create_partitioned(extended, nb, Alpha, Beta, 0, &ve);
+  if (rc != STFEM_OK) return rc;
+  if (!ve->per_cell) { // an axis-aligned uniform mesh: the class variant handles the partition by itself
+    stfem_vanka_destroy(ve);
+    return stfem_vanka_create_partitioned(slab, nb, Alpha, Beta, neighbour_mask, out);
+  }
+  stfem_vanka *v = new (std::nothrow) stfem_vanka;
+  if (!v) {
+    stfem_vanka_destroy(ve);
+    return STFEM_ERR_OUT_OF_MEMORY;
+  }
+  v->ctx = slab; v->nb = ve->nb; v->nloc = ve->nloc; v->m = ve->m;
+  v->mt = ve->mt; v->mtw = ve->mtw; v->parts = ve->parts; v->mpad = ve->mpad; v->kpad = ve->kpad;
+  v->per_cell = true;
+  v->nclasses = int(slab->ncells);
+  // take the allocation over; the slab's cells start behind the lower ghost layer
+  v->d_blocks_base = ve->d_blocks;
+  ve->d_blocks = nullptr;
+  const size_t bsz = size_t(v->kpad) * v->mpad;
+  v->d_blocks = static_cast<char *>(v->d_blocks_base) + size_t(glo) * size_t(slab->nc[0]) * slab->nc[1] * bsz * slab->es;
+  stfem_vanka_destroy(ve);
+  VK_TRY(hipSetDevice(slab->device));
+  rc = vanka_per_cell_tables(v);
+  if (rc != STFEM_OK) {
+    stfem_vanka_destroy(v);
+    return rc;
+  }
+  *out = v;
+  return STFEM_OK;
+}
+
 void stfem_vanka_destroy(stfem_vanka *v)
 {
   if (!v) return;
   (void)hipSetDevice(v->ctx->device);
-  if (v->d_blocks) (void)hipFree(v->d_blocks);
+  if (v->d_blocks_base) (void)hipFree(v->d_blocks_base);
+  else if (v->d_blocks) (void)hipFree(v->d_blocks);
   if (v->d_off) (void)hipFree(v->d_off);
   for (int i = 0; i < 8; ++i) {
     if (v->d_cell[i]) (void)hipFree(v->d_cell[i]);

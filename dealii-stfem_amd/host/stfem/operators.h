@@ -88,6 +88,11 @@ public:
     ctx_->upper_rank = upper_rank;
   }
 
+  // General (perturbed) meshes on a partition: the mesh of this slab plus ONE ghost cell layer on every side with a neighbour rank
+  // (vertices of the neighbour's first cell layer; Mesh::dirichlet_mask as the slab's).  The reference's smoother builds its cell
+  // blocks on locally owned and ghost cells (stmg.h:688-689, 795-796); PreconditionVanka does the same from this mesh.
+  void set_ghost_layers(const Mesh &extended_mesh) { ctx_->extended = make_context(extended_mesh, ctx_->degree); }
+
   void vmult(VectorType &dst, const VectorType &src, void *stream = nullptr) const
   {
     ghost_update(*ctx_, src.handle(), stream);
@@ -287,7 +292,9 @@ public:
     stfem_vanka *v = nullptr;
     // on a slab of a partitioned mesh (MatrixFreeOperator::set_partition BEFORE this constructor) the cells behind the interface faces count
     const int neighbours = (ctx_->lower_rank >= 0 ? 16 : 0) | (ctx_->upper_rank >= 0 ? 32 : 0);
-    const int rc = stfem_vanka_create_partitioned(ctx_->h, int(Alpha.m()), a.data(), b.data(), neighbours, &v);
+    const int rc = (neighbours && ctx_->extended)
+                     ? stfem_vanka_create_partitioned_general(ctx_->h, ctx_->extended->h, int(Alpha.m()), a.data(), b.data(), neighbours, &v)
+                     : stfem_vanka_create_partitioned(ctx_->h, int(Alpha.m()), a.data(), b.data(), neighbours, &v);
     if (rc != STFEM_OK) throw Error(rc, std::string("stfem_vanka_create: ") + stfem_vanka_last_error());
     v_.reset(v, stfem_vanka_destroy);
   }

@@ -148,6 +148,9 @@ struct Context {
   std::shared_ptr<Communicator> comm;
   int lower_rank = -1, upper_rank = -1;
   unsigned degree = 0; // FE_Q(degree) in space
+  // general meshes on a partition: the same slab plus one ghost cell layer per interface (MatrixFreeOperator::set_ghost_layers):
+  // what the cell-patch smoother builds its blocks on (stmg.h:688-689: locally owned and ghost cells)
+  std::shared_ptr<Context> extended;
   explicit Context(stfem_ctx *c) : h(c) {}
   ~Context() { stfem_ctx_destroy(h); }
   Context(const Context &) = delete;

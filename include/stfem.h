@@ -289,9 +289,17 @@ int stfem_vanka_create(stfem_ctx *ctx, int n, const double *alpha, const double 
 /* the same on one slab of a partitioned mesh: neighbour_mask (bits as dirichlet_mask) names the faces behind which another rank
  * holds the next cells.  The blocks and valences of the cells at such a face count the cells beyond it, as the reference's do on
  * a parallel::distributed::Triangulation (ghost cells); stfem_vanka_vmult then leaves PARTIAL sums in the interface planes of
- * dst, to be completed by the add-exchange of the operator (stfem_halo_begin / end).  Axis-aligned uniform meshes only
- * (STFEM_ERR_UNSUPPORTED for one-block-per-cell contexts). */
+ * dst, to be completed by the add-exchange of the operator (stfem_halo_begin / end).  Axis-aligned uniform meshes; for
+ * one-block-per-cell contexts (STFEM_ERR_UNSUPPORTED here) see stfem_vanka_create_partitioned_general. */
 int stfem_vanka_create_partitioned(stfem_ctx *ctx, int n, const double *alpha, const double *beta, int neighbour_mask, stfem_vanka **out);
+/* The same on a z-slab of a GENERAL mesh (perturbed cells, coefficient tables - BASELINE configs[2] on several ranks), where the
+ * blocks of the cells next to an interface need the cell matrices of the neighbour rank's cells (the reference builds its blocks
+ * on owned and ghost cells, stmg.h:688-689, 795-796; compute_block_matrix.h:68-73).  `extended` is a context of the same slab
+ * plus ONE ghost cell layer on every z side named in neighbour_mask (bit 4: lower, bit 5: upper) - same degree, precision and
+ * x-y constraints, no constraint on a z face with a ghost layer; the vertices of the ghost layers are all that crosses the
+ * ranks.  It may be destroyed after the call.  On axis-aligned uniform meshes this is stfem_vanka_create_partitioned. */
+int stfem_vanka_create_partitioned_general(stfem_ctx *slab, stfem_ctx *extended, int n, const double *alpha, const double *beta,
+                                           int neighbour_mask, stfem_vanka **out);
 void stfem_vanka_destroy(stfem_vanka *v);
 int stfem_vanka_n_classes(const stfem_vanka *v); /* distinct cell blocks held */
 /* diagnostics: {row tiles (16 rows) per workgroup, parts per cell block} */

@@ -176,6 +176,85 @@ def test_partitioned_vanka_on_one_gpu(stfem, p, gnc, world, number):
         stfem.PreconditionVanka(pert, Alpha, Beta, neighbour_mask=32)
 
 
+def _exchange_add(stfem, ranks, nb, plane, esz):
+    """the add-exchange of the interface planes between slab contexts on one device: pack -> device copy -> unpack-add"""
+    import ctypes
+    L = stfem.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["ts"], None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_pack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["bs"], None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for r, R in enumerate(ranks):
+        if R["slab"].has_upper:
+            assert hip.hipMemcpy(ranks[r + 1]["bufs"]["br"], R["bufs"]["ts"], nb * plane * esz, 3) == 0
+        if R["slab"].has_lower:
+            assert hip.hipMemcpy(ranks[r - 1]["bufs"]["tr"], R["bufs"]["bs"], nb * plane * esz, 3) == 0
+    for R in ranks:
+        if R["slab"].has_upper:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, R["nzl"] - 1, R["bufs"]["tr"], 1, None) == 0
+        if R["slab"].has_lower:
+            assert L.stfem_plane_unpack(R["ctx"]._h, R["dst"]._h, 0, R["bufs"]["br"], 1, None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("p,gnc,world,number,coef", [(2, (4, 3, 6), 2, "double", False), (4, (3, 2, 6), 3, "double", False), (3, (3, 2, 5), 2, "float", False),
+                                                      (2, (3, 3, 7), 3, "double", True)])
+def test_partitioned_per_cell_vanka_on_one_gpu(stfem, p, gnc, world, number, coef):
+    """One Vanka block per cell on z-slabs of a PERTURBED mesh (BASELINE configs[2] on several ranks;
+    stfem_vanka_create_partitioned_general): the blocks of the cells next to an interface are built with the neighbour rank's cells
+    from a context that carries one ghost cell layer (the reference builds them on owned and ghost cells, stmg.h:688-689, 795-796);
+    slab smoother + add-exchange == the smoother of the whole mesh."""
+    dmod = importlib.import_module("dealii-stfem_amd.distributed")
+    esz = 8 if number == "double" else 4
+    tol = 1e-11 if number == "double" else 5e-5
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    plane = (p * gnc[0] + 1) * (p * gnc[1] + 1)
+    ndofs = plane * (p * gnc[2] + 1)
+    cpl = gnc[0] * gnc[1]
+    X = np.random.default_rng(3).uniform(-1, 1, (nb, ndofs))
+    if number == "float":
+        X = X.astype(np.float32).astype(float)
+    verts = lambda z0, z1: stfem.mesh_vertices(gnc, (0, 0, 0), (1, 1, 1.5), 0.15, 5489, z_range=(z0, z1))  # noqa: E731
+    cvals = np.random.default_rng(8).uniform(0.5, 3.0, cpl * gnc[2])  # a cell-wise coefficient on K (then the extended context needs it too)
+    gctx = stfem.MatrixFreeOperator(p, gnc, vertices=verts(0, gnc[2]), number=number)
+    if coef:
+        gctx.evaluate_coefficient(cvals, which=1)
+    gV = stfem.PreconditionVanka(gctx, Alpha, Beta)
+    assert gV.n_classes == gctx.n_cells  # one block per cell
+    gdst = stfem.BlockVector(gctx, nb)
+    gV.vmult(gdst, stfem.BlockVector(gctx, nb).upload(X))
+    Y = gdst.download()
+    ranks = []
+    for r in range(world):
+        slab = dmod.make_slab(gnc, r, world)
+        ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=verts(slab.z0, slab.z1), number=number, dirichlet_mask=slab.dirichlet_mask(63))
+        e0, e1 = slab.z0 - (1 if slab.has_lower else 0), slab.z1 + (1 if slab.has_upper else 0)
+        ext = stfem.MatrixFreeOperator(p, (gnc[0], gnc[1], e1 - e0), vertices=verts(e0, e1), number=number, dirichlet_mask=slab.dirichlet_mask(63))
+        if coef:
+            ctx.evaluate_coefficient(cvals[cpl * slab.z0:cpl * slab.z1], which=1)
+            ext.evaluate_coefficient(cvals[cpl * e0:cpl * e1], which=1)
+        nmask = (16 if slab.has_lower else 0) | (32 if slab.has_upper else 0)
+        V = stfem.PreconditionVanka(ctx, Alpha, Beta, neighbour_mask=nmask, extended=ext)
+        del ext  # (may be destroyed after the call)
+        lo, hi = p * slab.z0 * plane, (p * slab.z1 + 1) * plane
+        dst = stfem.BlockVector(ctx, nb)
+        V.vmult(dst, stfem.BlockVector(ctx, nb).upload(X[:, lo:hi]))
+        hold = stfem.BlockVector(ctx, 4)
+        ranks.append(dict(slab=slab, ctx=ctx, V=V, dst=dst, hold=hold, nzl=p * (slab.z1 - slab.z0) + 1, lo=lo, hi=hi,
+                          bufs={k: hold.block_ptr(q) for q, k in enumerate(("ts", "bs", "tr", "br"))}))
+    _exchange_add(stfem, ranks, nb, plane, esz)
+    for R in ranks:
+        assert rel(R["dst"].download(), Y[:, R["lo"]:R["hi"]]) < tol
+    # an extended context of the wrong shape is refused
+    with pytest.raises(stfem.StfemError):
+        stfem.PreconditionVanka(ranks[0]["ctx"], Alpha, Beta, neighbour_mask=32, extended=ranks[0]["ctx"])
+
+
 @pytest.mark.parametrize("pf,pc,gf,gc,world,number", [(2, 2, (4, 4, 8), (2, 2, 4), 2, "double"), (4, 2, (2, 3, 6), (2, 3, 6), 3, "double"),
                                                        (3, 3, (2, 2, 12), (1, 1, 6), 3, "float")])
 def test_partitioned_space_transfer_on_one_gpu(stfem, pf, pc, gf, gc, world, number):
@@ -238,3 +317,117 @@ def test_partitioned_space_transfer_on_one_gpu(stfem, pf, pc, gf, gc, world, num
     assert hip.hipDeviceSynchronize() == 0
     for R in ranks:
         assert rel(R["dst"].download(), RX[:, R["lo"]:R["hi"]]) < tol
+
+
+class _SlabLevels:
+    """A two- or three-level space multigrid on `world` z-slabs of one mesh, every slab with its own contexts on the same device and the
+    interface planes exchanged by pack -> copy -> unpack-add: the operations a rank of the partitioned C++ mirror performs
+    (host/stfem/stmg.h: level operator with its add-exchange, partitioned Vanka relaxation, local prolongation, restriction with partial
+    sums in the coarse interface planes).  world = 1 is the whole mesh through the same code."""
+
+    def __init__(self, stfem, gnc_fine, degrees, world, distort, Alpha, Beta, number="double"):
+        self.stfem, self.dmod = stfem, importlib.import_module("dealii-stfem_amd.distributed")
+        self.nb, self.world, self.esz = Alpha.shape[0], world, 8 if number == "double" else 4
+        self.levels = []  # coarsest first: list over levels of list over ranks
+        n_levels = len(degrees)
+        for l in range(n_levels):
+            f = 2 ** (n_levels - 1 - l)  # cells of this level are f fine cells wide
+            gnc = tuple(c // f for c in gnc_fine)
+            p = degrees[l]
+            plane = (p * gnc[0] + 1) * (p * gnc[1] + 1)
+
+            def verts(z0, z1, f=f, gnc=gnc):  # every f-th vertex plane / row / column of the fine mesh
+                v = stfem.mesh_vertices(gnc_fine, (0, 0, 0), (1, 1, 1.5), distort, 5489, z_range=(f * z0, f * z1))
+                v = v.reshape(f * (z1 - z0) + 1, gnc_fine[1] + 1, gnc_fine[0] + 1, 3)[::f, ::f, ::f]
+                return np.ascontiguousarray(v).reshape(-1, 3)
+            ranks = []
+            for r in range(world):
+                slab = self.dmod.make_slab(gnc, r, world)
+                ctx = stfem.MatrixFreeOperator(p, slab.ncell, vertices=verts(slab.z0, slab.z1), number=number, dirichlet_mask=slab.dirichlet_mask(63))
+                nmask = (16 if slab.has_lower else 0) | (32 if slab.has_upper else 0)
+                ext = None
+                if nmask:
+                    e0, e1 = slab.z0 - (1 if slab.has_lower else 0), slab.z1 + (1 if slab.has_upper else 0)
+                    ext = stfem.MatrixFreeOperator(p, (gnc[0], gnc[1], e1 - e0), vertices=verts(e0, e1), number=number, dirichlet_mask=slab.dirichlet_mask(63))
+                hold = stfem.BlockVector(ctx, 4 if self.nb <= 4 else self.nb * 4)
+                ranks.append(dict(slab=slab, ctx=ctx, A=stfem.SystemMatrix(ctx, Alpha, Beta), V=stfem.PreconditionVanka(ctx, Alpha, Beta, neighbour_mask=nmask, extended=ext),
+                                  nmask=nmask, plane=plane, nzl=p * (slab.z1 - slab.z0) + 1, lo=p * slab.z0 * plane, hi=(p * slab.z1 + 1) * plane, hold=hold,
+                                  bufs={k: hold.block_ptr(q) for q, k in enumerate(("ts", "bs", "tr", "br"))}))
+            self.levels.append(ranks)
+        self.T = [None] + [[stfem.MGTwoLevelTransfer(fr["ctx"], cr["ctx"], neighbour_mask=fr["nmask"]) for fr, cr in zip(self.levels[l], self.levels[l - 1])]
+                           for l in range(1, n_levels)]
+
+    def vec(self, l):
+        return [self.stfem.BlockVector(R["ctx"], self.nb) for R in self.levels[l]]
+
+    def compress(self, l, v):
+        if self.world > 1:
+            ranks = [dict(R, dst=x) for R, x in zip(self.levels[l], v)]
+            _exchange_add(self.stfem, ranks, self.nb, self.levels[l][0]["plane"], self.esz)
+
+    def axpby(self, l, a, x, b, y):
+        L = self.stfem.lib()
+        for R, xi, yi in zip(self.levels[l], x, y):
+            assert L.stfem_vector_axpby(R["ctx"]._h, a, xi._h, b, yi._h, None) == 0
+
+    def vmult(self, l, dst, src):
+        for R, d, s in zip(self.levels[l], dst, src):
+            R["A"].vmult(d, s)
+        self.compress(l, dst)
+
+    def relax(self, l, dst, src, omega):  # dst = omega P^-1 src
+        for R, d, s in zip(self.levels[l], dst, src):
+            R["V"].vmult(d, s)
+        self.compress(l, dst)
+        self.axpby(l, 0.0, dst, omega, dst)
+
+    def v_cycle(self, l, u, d, omega):
+        """Multigrid::level_v_step with one relaxation step per level (from zero before, one more after the coarse correction)"""
+        self.relax(l, u, d, omega)
+        if l == 0:
+            return
+        t, dc, uc = self.vec(l), self.vec(l - 1), self.vec(l - 1)
+        self.vmult(l, t, u)
+        self.axpby(l, 1.0, d, -1.0, t)                     # t = d - A u
+        for T, c, f in zip(self.T[l], dc, t):               # restriction: partial sums in the coarse interface planes
+            T.restrict_and_add(c, f)
+        self.compress(l - 1, dc)
+        self.v_cycle(l - 1, uc, dc, omega)
+        for T, f, c in zip(self.T[l], t, uc):               # prolongation: local
+            T.prolongate(f, c)
+        self.axpby(l, 1.0, t, 1.0, u)
+        self.vmult(l, t, u)
+        self.axpby(l, 1.0, d, -1.0, t)
+        r = self.vec(l)
+        self.relax(l, r, t, omega)
+        self.axpby(l, 1.0, r, 1.0, u)
+
+
+@pytest.mark.parametrize("gnc,degrees,world,distort", [((4, 4, 8), (2, 2), 2, 0.0), ((4, 4, 12), (1, 2, 2), 3, 0.0), ((4, 4, 8), (2, 2), 2, 0.12),
+                                                       ((4, 4, 12), (2, 2, 2), 3, 0.1)])
+def test_v_cycle_on_slabs_equals_whole_mesh(stfem, gnc, degrees, world, distort):
+    """One full V-cycle (level operators, Vanka relaxation, restriction, prolongation) on 2 and 3 z-slabs with the interface planes
+    exchanged == the same cycle on the whole mesh: uniform meshes (block classes) and perturbed ones (one block per cell, ghost cell
+    layers: the configs[2] situation on several ranks).  Every level halves the cells; degrees (1, 2, 2): the coarsest transfer
+    changes mesh and degree at once."""
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    whole = _SlabLevels(stfem, gnc, degrees, 1, distort, Alpha, Beta)
+    parts = _SlabLevels(stfem, gnc, degrees, world, distort, Alpha, Beta)
+    top = len(degrees) - 1
+    n = whole.levels[top][0]["ctx"].n_dofs
+    X = np.random.default_rng(12).uniform(-1, 1, (nb, n))
+    # a right-hand side of the constrained space, as FGMRES hands one over: A x
+    x, d, u = whole.vec(top), whole.vec(top), whole.vec(top)
+    x[0].upload(X)
+    whole.vmult(top, d, x)
+    D = d[0].download()
+    whole.v_cycle(top, u, d, 0.7)
+    U = u[0].download()
+    assert np.linalg.norm(U) > 0
+    dp, up = parts.vec(top), parts.vec(top)
+    for R, v in zip(parts.levels[top], dp):
+        v.upload(D[:, R["lo"]:R["hi"]])
+    parts.v_cycle(top, up, dp, 0.7)
+    for R, v in zip(parts.levels[top], up):
+        assert rel(v.download(), U[:, R["lo"]:R["hi"]]) < 1e-10
