@@ -97,6 +97,16 @@ template <typename T> __device__ __forceinline__ void vm_store_masked(T *p, T v,
                  : "=&s"(save) : "v"(p), "v"(v), "s"(mask) : "memory");
 }
 template <int CNT> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); }
+#ifdef STFEM_PENCIL_TOUCH
+// experiment (tools/build_pencil_exp.sh -DSTFEM_PENCIL_TOUCH): a few lanes per row touch the src lines of the cell group AFTER
+// the next one (a 4-byte load into a register nobody reads), so that the real loads, one group later, find them in L2
+__device__ __forceinline__ void vm_touch(float &sink, const void *p, unsigned long long mask)
+{
+  unsigned long long save;
+  asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_load_dword %0, %2, off\n\ts_mov_b64 exec, %1"
+               : "+v"(sink), "=&s"(save) : "v"(p), "s"(mask) : "memory");
+}
+#endif
 
 template <int P, int NBM, int TY> struct PencilGeom {
   using G = Geometry<P, NBM>;
@@ -293,6 +303,11 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
     }
   };
   const unsigned long long st_mask = __builtin_amdgcn_ballot_w64((lf & LF_ST) != 0);
+#ifdef STFEM_PENCIL_TOUCH
+  // one lane per 128-byte line of a block's row: X = 0, 16 and the last column
+  const unsigned long long touch_mask = __builtin_amdgcn_ballot_w64((lf & LF_IN) && (X == 0 || X == 16 || X == P * (nslot - 1) + P));
+  float touch_sink = 0.0f;
+#endif
   real_t sink = real_t(0); // experiments only
   auto put = [&](real_t *q, real_t v) {
     if (PEX & 1) sink += v;
@@ -404,6 +419,23 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
       }
       PTL(3);
 
+#ifdef STFEM_PENCIL_TOUCH
+      // the group after the next one
+      const int g2 = cyl + 2, l2 = layer + g2 / ncy_t, c2 = g2 % ncy_t;
+      const bool has_next2 = l2 < nlay;
+      const real_t *tn = src_lane + plane_stride * (int64_t(P) * l2) + int64_t(prm.nx) * (int64_t(P) * c2);
+      asm volatile("" : "+v"(tn));
+      auto touch_row = [&](int y) {
+        if (!has_next2) return;
+        const real_t *q = tn;
+        STFEM_UNROLL
+        for (int z = 0; z < N; ++z) {
+          vm_touch(touch_sink, q, touch_mask);
+          if (z + 1 < N) step(q, plane_stride);
+        }
+        step(tn, prm.nx);
+      };
+#endif
       // finished rows leave as they come out of the last sweep: y, z in [0, P).  The y = 0 row of a
       // pencil with a wave below is kept back for one layer.
       const bool defer = has_lower && cyl == 0;
@@ -413,6 +445,9 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
       real_t *drow = d; // walks from row to row
       real_t znew[P];
       auto row_done = [&](int y, real_t (&r)[N]) {
+#ifdef STFEM_PENCIL_TOUCH
+        touch_row(y);
+#endif
         if (masked) {
           STFEM_UNROLL
           for (int z = 0; z < N; ++z)
@@ -474,6 +509,9 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
       // the prefetched src planes are older than this group's dst stores
       if (ASYNC && !(PEX & 2)) {
         if (PEX & 1) vm_wait<0>();
+#ifdef STFEM_PENCIL_TOUCH
+        else if (has_next2) vm_wait<MAIN_STORES_MIN + NN>(); // the touches are younger than the prefetched planes too
+#endif
         else vm_wait<MAIN_STORES_MIN>();
         pin(PA);
         asm volatile("" : "+v"(fK), "+v"(fM));
@@ -524,6 +562,9 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
     }
   }
   if (PEX && sink == real_t(1.2345e30)) pp.zh[0] = sink; // experiment sink, never true
+#ifdef STFEM_PENCIL_TOUCH
+  asm volatile("" ::"v"(touch_sink)); // (the register stays reserved while touches can be in flight)
+#endif
 
   // last layer's kept-back row, and the y = 0 row of the chunk's top plane
   if (has_lower && ncy_t > 0) {
