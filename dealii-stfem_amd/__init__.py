@@ -148,6 +148,7 @@ SIGNATURES = {
                                              C.c_double, C.c_double, C.POINTER(C.c_int32), _dp,
                                              _dp, _dp]),
     "stfem_stokes_create": (C.c_int, [C.POINTER(_MeshDesc), C.c_int, C.c_double, C.POINTER(_vp)]),
+    "stfem_stokes_create_ex": (C.c_int, [C.POINTER(_MeshDesc), C.c_int, C.c_int, C.c_double, C.POINTER(_vp)]),
     "stfem_stokes_destroy": (None, [_vp]),
     "stfem_stokes_n_velocity_dofs": (C.c_int64, [_vp]),
     "stfem_stokes_n_pressure_dofs": (C.c_int64, [_vp]),
@@ -654,7 +655,7 @@ class StokesMatrixFreeOperator:
 
     def __init__(self, ncell, vertices=None, lower=(0, 0, 0), upper=(1, 1, 1), dirichlet_mask=63,
                  viscosity=1.0, velocity_degree=2, device=0, weak_boundary_ids=(), outflow_boundary_ids=(),
-                 penalty1=20.0, penalty2=10.0):
+                 penalty1=20.0, penalty2=10.0, dg_pressure=False):
         """weak_boundary_ids / outflow_boundary_ids: boundary ids 0..5 (face 2 d + s) as in the reference's constructor
         (operators.h:1206-1211); penalty1 / penalty2: its Nitsche penalties (gamma1 = viscosity penalty1, gamma2 = penalty2)."""
         m = _MeshDesc()
@@ -669,7 +670,8 @@ class StokesMatrixFreeOperator:
         m.dirichlet_mask = dirichlet_mask
         m.device = device
         h = _vp()
-        _check(lib().stfem_stokes_create(C.byref(m), velocity_degree, viscosity, C.byref(h)),
+        # dg_pressure: FE_DGP(1) instead of FE_Q(1) (the reference's dGPressure, tests/tp_03stokes.cc:83-86)
+        _check(lib().stfem_stokes_create_ex(C.byref(m), velocity_degree, 1 if dg_pressure else 0, viscosity, C.byref(h)),
                "stfem_stokes_create")
         self._h = h
         self.n_velocity = lib().stfem_stokes_n_velocity_dofs(h)
@@ -720,6 +722,27 @@ class StokesMatrixFreeOperator:
         s_ = (_vp * nb)(*[getattr(v, "ptr", v) for v in src_blocks])
         _check(lib().stfem_stokes_st_vmult(self._h, n_timesteps_at_once, n_timedofs, int(variable_major),
                                            _p(A), _p(B), d, s_, stream), "stfem_stokes_st_vmult")
+
+    def st_Tvmult(self, Alpha, Beta, n_timesteps_at_once, n_timedofs, dst_blocks, src_blocks, variable_major=True, stream=None):
+        """SystemMatrixStokes::Tvmult AS THE REFERENCE HAS IT (operators.h:708-745): its scatter overload (operators.h:111-123)
+        takes j = index(it, v, id), i = index(jt, v, jd), so the result of source time dof (it, id) only goes to the destination
+        blocks of the same time dof, weighted with the entries of row j summed over the time dofs - not a transpose.  Expressed
+        with the effective matrices of that rule and run as one st_vmult."""
+        nt, ns = n_timedofs, n_timesteps_at_once
+        nb = 2 * nt * ns
+        A = np.asarray(Alpha, dtype=np.float64); B = np.asarray(Beta, dtype=np.float64)
+        eps10 = 10 * np.finfo(np.float64).eps
+        Ae, Be = np.zeros((nb, nb)), np.zeros((nb, nb))
+        idx = lambda it, v, d: stokes_block_index(nt, it, v, d, variable_major)  # noqa: E731
+        for it in range(ns):
+            for d in range(nt):
+                col = idx(it, 0, d)  # the velocity column drives the scatters of st_vmult
+                for v in range(2):
+                    j = idx(it, v, d)
+                    Ae[j, col] = sum(A[j, idx(jt, v, jd)] for jt in range(ns) for jd in range(nt) if abs(A[j, idx(jt, v, jd)]) > eps10)
+                j = idx(it, 0, d)
+                Be[j, col] = sum(B[j, idx(jt, 0, jd)] for jt in range(ns) for jd in range(nt) if abs(B[j, idx(jt, 0, jd)]) > eps10)
+        self.st_vmult(Ae, Be, ns, nt, dst_blocks, src_blocks, variable_major, stream)
 
     def st_vmult_slice_add(self, Gamma, Zeta, n_timesteps_at_once, n_timedofs, dst_blocks, src_u, src_p,
                            variable_major=True, stream=None):

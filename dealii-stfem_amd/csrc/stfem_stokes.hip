@@ -59,6 +59,10 @@ struct StokesParams {
   int store_u[MAXOUT], store_p[MAXOUT]; // 1: the first cell to touch a DoF (lowest colour) stores, the others add; 0: all add
   int cart;                   // axis-aligned uniform cells: constant diagonal Jacobian
   double hinv[3], detJ;       // 1 / h_d, hx hy hz
+  // pressure space: 0 = FE_Q(1) on the vertex lattice, 1 = FE_DGP(1), the reference's dGPressure (tests/tp_03stokes.cc:83-86):
+  // four DoFs per cell, deal.II's basis 1, l(xi), l(eta), l(zeta) with l(x) = sqrt 3 (2 x - 1), p[cell * 4 + j]
+  int pdg;
+  double l1q[3];              // l at the three Gauss points
 };
 
 __device__ __forceinline__ bool constrained_u(const StokesParams &prm, int ix, int iy, int iz)
@@ -114,7 +118,10 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
 #pragma unroll
   for (int n = 0; n < 2; ++n) { Pa[n] = tP[a * 2 + n]; Pb[n] = tP[b * 2 + n]; Pc[n] = tP[c * 2 + n]; }
   const double wabc = prm.wq[a] * prm.wq[b] * prm.wq[c];
-  const bool pnode = lane27 && a < 2 && b < 2 && c < 2; // this lane also integrates pressure node (a, b, c)
+  // this lane also carries a pressure DoF of the cell: FE_Q(1) node (a, b, c), or FE_DGP(1) function t
+  const bool pnode = prm.pdg ? t32 < 4 : (lane27 && a < 2 && b < 2 && c < 2);
+  const int pslot = prm.pdg ? t32 : a + 2 * b + 4 * c; // its slot in the cell's pressure values X[81 ..]
+  const double la = prm.l1q[a], lb = prm.l1q[b], lc = prm.l1q[c]; // DGP: the linear functions at this lane's quadrature point
   // the cells of one colour share no DoF: the eight colours run as eight launches, lowest first, and
   // scatter with plain loads and stores (no atomics, no zeroing of the destinations, deterministic)
   const int px = prm.colour & 1, py = (prm.colour >> 1) & 1, pz = prm.colour >> 2;
@@ -144,7 +151,8 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     const int ix = 2 * q.cx + a, iy = 2 * q.cy + b, iz = 2 * q.cz + c;
     q.con = constrained_u(prm, ix, iy, iz);
     q.gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
-    q.gp = (q.cx + a1) + (long long)prm.ndp[0] * ((q.cy + b1) + (long long)prm.ndp[1] * (q.cz + c1));
+    q.gp = prm.pdg ? (q.cx + (long long)prm.ncx * (q.cy + (long long)prm.ncy * q.cz)) * 4 + (t32 & 3)
+                   : (q.cx + a1) + (long long)prm.ndp[0] * ((q.cy + b1) + (long long)prm.ndp[1] * (q.cz + c1));
     return q;
   };
   double un[3] = {0, 0, 0}, pn = 0.0;
@@ -180,10 +188,15 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
 #pragma unroll
       for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = un[comp];
     }
-    if (pnode) X[81 + a + 2 * b + 4 * c] = pn;
+    if (pnode) X[81 + pslot] = pn;
     nxt = ids(first + STRIDE * ((it2 + 1) / nsrc));
     fetch(nxt, int((it2 + 1) % nsrc));
     wave_fence();
+    double pdgv[4] = {0, 0, 0, 0};
+    if (prm.pdg) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pdgv[j] = X[81 + j];
+    }
 
     // ---- evaluate, x: (n_x, n_y, n_z) -> (q_x, n_y, n_z): values and x derivatives -> Y
 #pragma unroll
@@ -217,7 +230,8 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       gref[comp][1] = fma(Sc[2], dy[18], fma(Sc[1], dy[9], Sc[0] * dy[0]));
       gref[comp][2] = fma(Dc[2], v2, fma(Dc[1], v1, Dc[0] * v0));
     }
-    const double pval = fma(Pc[1], X[243 + a + 3 * b + 9], Pc[0] * X[243 + a + 3 * b]);
+    double pval = fma(Pc[1], X[243 + a + 3 * b + 9], Pc[0] * X[243 + a + 3 * b]);
+    if (prm.pdg) pval = pdgv[0] + la * pdgv[1] + lb * pdgv[2] + lc * pdgv[3];
 
     // ---- quadrature-point operation (operators.h:1547-1553, 1570; weights applied at scatter time) -> Y
     if (CART) {
@@ -283,6 +297,15 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       Y[9 * 27 + t] = divu * JxW;
     }
     wave_fence();
+    double rPdg = 0.0;
+    if (prm.pdg && t32 < 4) { // (q_j, div u): the cell's own four test functions, summed over the 27 quadrature points
+      const double *fd = Y + 9 * 27;
+      for (int q = 0; q < 27; ++q) {
+        const int qa = q % 3, qb = (q / 3) % 3, qc = q / 9;
+        const double l = t32 == 0 ? 1.0 : prm.l1q[t32 == 1 ? qa : (t32 == 2 ? qb : qc)];
+        rPdg = fma(l, fd[q], rPdg);
+      }
+    }
 
     // ---- integrate, z: quadrature point -> (q_x, q_y, n_z) -> X
 #pragma unroll
@@ -321,7 +344,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       rM[comp] = fma(SaT[2], hm[2], fma(SaT[1], hm[1], SaT[0] * hm[0]));
     }
     const double *hd = Y + 243 + 3 * b + 9 * c;
-    const double rP = fma(PaT[2], hd[2], fma(PaT[1], hd[1], PaT[0] * hd[0]));
+    const double rP = prm.pdg ? rPdg : fma(PaT[2], hd[2], fma(PaT[1], hd[1], PaT[0] * hd[0]));
 
     // ---- distribute_local_to_global: constrained velocity rows stay 0.  A DoF on a face shared with a
     // neighbouring cell is first touched by the cell whose colour bits are 0 in all shared directions.
@@ -339,9 +362,9 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       const bool fu = !((a == 0 && cx > 0 && px) || (a == 2 && cx < prm.ncx - 1 && px) ||
                         (b == 0 && cy > 0 && py) || (b == 2 && cy < prm.ncy - 1 && py) ||
                         (c == 0 && cz > 0 && pz) || (c == 2 && cz < prm.ncz - 1 && pz));
-      const bool fp = !((a == 0 && cx > 0 && px) || (a == 1 && cx < prm.ncx - 1 && px) ||
-                        (b == 0 && cy > 0 && py) || (b == 1 && cy < prm.ncy - 1 && py) ||
-                        (c == 0 && cz > 0 && pz) || (c == 1 && cz < prm.ncz - 1 && pz));
+      const bool fp = prm.pdg || !((a == 0 && cx > 0 && px) || (a == 1 && cx < prm.ncx - 1 && px) ||
+                                    (b == 0 && cy > 0 && py) || (b == 1 && cy < prm.ncy - 1 && py) ||
+                                    (c == 0 && cz > 0 && pz) || (c == 1 && cz < prm.ncz - 1 && pz));
       if constexpr (FUSED) {
 #pragma unroll
         for (int o = 0; o < MAXSRC; ++o)
@@ -426,7 +449,8 @@ __global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams
   const bool lane27 = t32 < 27;
   const int t = lane27 ? t32 : 0;
   const int a = t % 3, b = (t / 3) % 3, c = t / 9;
-  const bool pnode = lane27 && a < 2 && b < 2 && c < 2;
+  const bool pnode = prm.pdg ? t32 < 4 : (lane27 && a < 2 && b < 2 && c < 2);
+  const int pslot = prm.pdg ? t32 : a + 2 * b + 4 * c;
   const int nc[3] = {prm.ncx, prm.ncy, prm.ncz};
   double *X = sX[slot];
   for (long long item = (long long)blockIdx.x * 8 + slot; item - slot < bp.foff[6]; item += (long long)gridDim.x * 8) {
@@ -456,7 +480,8 @@ __global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams
     const int ix = 2 * cx + a, iy = 2 * cy + b, iz = 2 * cz + c;
     const bool con = constrained_u(prm, ix, iy, iz);
     const long long gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
-    const long long gp = (cx + (a < 2 ? a : 1)) + (long long)prm.ndp[0] * ((cy + (b < 2 ? b : 1)) + (long long)prm.ndp[1] * (cz + (c < 2 ? c : 1)));
+    const long long gp = prm.pdg ? (cx + (long long)prm.ncx * (cy + (long long)prm.ncy * cz)) * 4 + (t32 & 3)
+                                 : (cx + (a < 2 ? a : 1)) + (long long)prm.ndp[0] * ((cy + (b < 2 ? b : 1)) + (long long)prm.ndp[1] * (cz + (c < 2 ? c : 1)));
     double accU[FUSED ? MAXSRC : 1][3], accP[FUSED ? MAXSRC : 1];
 #pragma unroll
     for (int o = 0; o < (FUSED ? MAXSRC : 1); ++o) accU[o][0] = accU[o][1] = accU[o][2] = accP[o] = 0.0;
@@ -466,7 +491,7 @@ __global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams
         const double *us = FUSED ? prm.us[src] : prm.u, *ps = FUSED ? prm.ps[src] : prm.p;
         if (lane27)
           for (int comp = 0; comp < 3; ++comp) X[comp * 27 + t] = (ok && !con) ? us[comp * prm.Nu + gu] : 0.0;
-        if (pnode) X[81 + a + 2 * b + 4 * c] = (ok && ps) ? ps[gp] : 0.0;
+        if (pnode) X[81 + pslot] = (ok && ps) ? ps[gp] : 0.0;
       }
       double rU[3] = {0, 0, 0}, rP = 0.0;
       for (int f = 0; f < 6; ++f) {
@@ -478,6 +503,13 @@ __global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams
         auto tv = [&](int dir, int qa, int qb, int n) { return dir == d ? tE[s * 3 + n] : tS[(dir == t1 ? qa : qb) * 3 + n]; };
         auto td = [&](int dir, int qa, int qb, int n) { return dir == d ? tED[s * 3 + n] : tD[(dir == t1 ? qa : qb) * 3 + n]; };
         auto tp = [&](int dir, int qa, int qb, int n) { return dir == d ? tEP[s * 2 + n] : tP[(dir == t1 ? qa : qb) * 2 + n]; };
+        // FE_DGP(1) function j at face point (qa, qb): 1, l(xi), l(eta), l(zeta), l(x) = sqrt 3 (2 x - 1)
+        auto dg = [&](int j, int qa, int qb) {
+          if (j == 0) return 1.0;
+          const int dir = j - 1;
+          const double x = dir == d ? double(s) : tX[dir == t1 ? qa : qb];
+          return 1.7320508075688772 * (2.0 * x - 1.0);
+        };
         double Ji[3][3], nrm[3], JxW = 0.0;
         if (on && t32 < 9) { // geometry of this lane's face point
           double xi[3];
@@ -551,6 +583,9 @@ __global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams
                     uval[comp] += w * sx * sy * sz;
                   }
                 }
+            if (prm.pdg) {
+              for (int j = 0; j < 4; ++j) pval += X[81 + j] * dg(j, q1, q2);
+            } else
             for (int kc = 0; kc < 2; ++kc)
               for (int kb = 0; kb < 2; ++kb)
                 for (int ka = 0; ka < 2; ++ka)
@@ -586,7 +621,7 @@ __global__ __launch_bounds__(256) void stokes_boundary_kernel(const StokesParams
             for (int k = 0; k < 3; ++k) dn += (gr[0] * G[k] + gr[1] * G[3 + k] + gr[2] * G[6 + k]) * G[9 + k];
             const double v = sx * sy * sz;
             for (int comp = 0; comp < 3; ++comp) rU[comp] += v * F[comp] + dn * F[3 + comp];
-            if (pnode) rP += tp(0, qa, qb, a) * tp(1, qa, qb, b) * tp(2, qa, qb, c) * F[6];
+            if (pnode) rP += (prm.pdg ? dg(t32 & 3, qa, qb) : tp(0, qa, qb, a) * tp(1, qa, qb, b) * tp(2, qa, qb, c)) * F[6];
           }
         }
         wave_fence(); // the next face reuses the point buffers
@@ -632,6 +667,7 @@ struct stfem_stokes_ctx {
   int n_cu = 256;
   StokesParams base;
   // weak (Nitsche) / outflow boundary faces (operators.h:1206-1211): bit f = 2 d + s
+  int pspace = 0; // 0 = FE_Q(1), 1 = FE_DGP(1)
   int weak_mask = 0, outflow_mask = 0;
   double penalty1 = 20.0, penalty2 = 10.0;
   BoundaryParams bnd;
@@ -656,7 +692,12 @@ const char *stfem_stokes_last_hip_error(void) { return g_stokes_err; }
 
 int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double viscosity, stfem_stokes_ctx **out)
 {
-  if (!mesh || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  return stfem_stokes_create_ex(mesh, velocity_degree, 0, viscosity, out);
+}
+
+int stfem_stokes_create_ex(const stfem_mesh_desc *mesh, int velocity_degree, int pressure_space, double viscosity, stfem_stokes_ctx **out)
+{
+  if (!mesh || !out || pressure_space < 0 || pressure_space > 1) return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   if (velocity_degree != 2) return STFEM_ERR_UNSUPPORTED; // Q2/Q1 (BASELINE configs[4]) only
   for (int d = 0; d < 3; ++d)
@@ -687,6 +728,8 @@ int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double
   }
   c->Nu = (long long)c->ndu[0] * c->ndu[1] * c->ndu[2];
   c->Np = (long long)c->ndp[0] * c->ndp[1] * c->ndp[2];
+  c->pspace = pressure_space;
+  if (pressure_space == 1) c->Np = 4ll * c->nc[0] * c->nc[1] * c->nc[2]; // FE_DGP(1): 1, x, y, z per cell
   const size_t nv = size_t(c->nc[0] + 1) * (c->nc[1] + 1) * (c->nc[2] + 1);
   std::vector<double> v(nv * 3);
   if (mesh->vertices) {
@@ -730,6 +773,8 @@ int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double
   b.dmask = c->dmask;
   b.nu = c->nu;
   b.cart = mesh->vertices ? 0 : 1;
+  b.pdg = c->pspace;
+  for (int i = 0; i < 3; ++i) b.l1q[i] = std::sqrt(3.0) * (2.0 * xq[i] - 1.0);
   b.interleave = 1;
   if (const char *e = getenv("STFEM_STOKES_INTERLEAVE")) b.interleave = atoi(e) != 0;
   b.detJ = 1.0;

@@ -8,6 +8,7 @@
 
 #include <array>
 #include <functional>
+#include <limits>
 #include <map>
 #include <set>
 
@@ -122,10 +123,12 @@ public:
 
   StokesMatrixFreeOperator(const Mesh &mesh, unsigned velocity_degree, Number viscosity, const std::set<boundary_id> &weak_boundary_ids = {},
                            const std::set<boundary_id> &outflow_boundary_ids = {}, Number penalty1 = 20, Number penalty2 = 10,
-                           Number /*outflow_penalty*/ = 0.0, Number delta0 = 0.0, Number /*delta1*/ = 0.0)
+                           Number /*outflow_penalty*/ = 0.0, Number delta0 = 0.0, Number /*delta1*/ = 0.0, bool dg_pressure = false)
   {
+    // dg_pressure: FE_DGP(degree - 1) instead of FE_Q(degree - 1) for the pressure (the reference chooses the element of its
+    // second DoFHandler, tests/tp_03stokes.cc:83-86: dGPressure)
     if (delta0 != 0.0) throw Error(STFEM_ERR_UNSUPPORTED, "StokesMatrixFreeOperator: the CIP face term (delta0 != 0) is not built");
-    create(mesh, velocity_degree, viscosity);
+    create(mesh, velocity_degree, viscosity, dg_pressure);
     int weak = 0, outflow = 0;
     for (boundary_id f : weak_boundary_ids) weak |= 1 << f;
     for (boundary_id f : outflow_boundary_ids) outflow |= 1 << f;
@@ -133,7 +136,7 @@ public:
   }
 
 private:
-  void create(const Mesh &mesh, unsigned velocity_degree, Number viscosity)
+  void create(const Mesh &mesh, unsigned velocity_degree, Number viscosity, bool dg_pressure)
   {
     stfem_mesh_desc md{};
     for (int d = 0; d < 3; ++d) {
@@ -144,7 +147,7 @@ private:
     md.vertices = mesh.vertices.empty() ? nullptr : mesh.vertices.data();
     md.dirichlet_mask = mesh.dirichlet_mask;
     md.device = mesh.device;
-    check(stfem_stokes_create(&md, int(velocity_degree), viscosity, &h_), "stfem_stokes_create");
+    check(stfem_stokes_create_ex(&md, int(velocity_degree), dg_pressure ? 1 : 0, viscosity, &h_), "stfem_stokes_create");
   }
 
 public:
@@ -239,6 +242,34 @@ public:
     check(stfem_stokes_st_vmult(K.handle(), int(blk_slice.n_timesteps_at_once()), int(blk_slice.n_timedofs()),
                                 blk_slice.variable_major() ? 1 : 0, Alpha.data(), Beta.data(), d.data(), s.data(), stream),
           "SystemMatrixStokes::vmult");
+  }
+  // operators.h:708-745, as the reference has it: its scatter overload (operators.h:111-123) reads j = index(it, v, id),
+  // i = index(jt, v, jd) - the result of source time dof (it, id) only reaches the destination blocks of the SAME time dof,
+  // weighted with the entries of row j summed over (jt, jd).  Not a transpose; reproduced as one vmult with those matrices.
+  void Tvmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    const unsigned nb = blk_slice.n_blocks(), ns = blk_slice.n_timesteps_at_once(), nt = blk_slice.n_timedofs();
+    if (dst.size() != nb || src.size() != nb || Alpha.n() != nb) throw Error(STFEM_ERR_SHAPE_MISMATCH, "SystemMatrixStokes::Tvmult");
+    const double eps10 = 10 * std::numeric_limits<Number>::epsilon();
+    FullMatrix<Number> Ae(nb, nb), Be(nb, nb);
+    for (unsigned it = 0; it < ns; ++it)
+      for (unsigned id = 0; id < nt; ++id) {
+        const unsigned col = blk_slice.index(it, 0, id);
+        for (unsigned v = 0; v < 2; ++v) {
+          const unsigned j = blk_slice.index(it, v, id);
+          for (unsigned jt = 0; jt < ns; ++jt)
+            for (unsigned jd = 0; jd < nt; ++jd) {
+              const unsigned i = blk_slice.index(jt, v, jd);
+              if (std::abs(Alpha(j, i)) > eps10) Ae(j, col) += Alpha(j, i);
+              if (v == 0 && std::abs(Beta(j, i)) > eps10) Be(j, col) += Beta(j, i);
+            }
+        }
+      }
+    std::vector<double *> d(nb);
+    std::vector<const double *> s(nb);
+    for (unsigned i = 0; i < nb; ++i) { d[i] = dst[i].data(); s[i] = src[i].data(); }
+    check(stfem_stokes_st_vmult(K.handle(), int(ns), int(nt), blk_slice.variable_major() ? 1 : 0, Ae.data(), Be.data(), d.data(), s.data(), stream),
+          "SystemMatrixStokes::Tvmult");
   }
   // n x 1 case for the right-hand side (operators.h:748-781): Alpha, Beta are n x 1 here and src is one
   // (velocity, pressure) pair; dst is accumulated into

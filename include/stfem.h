@@ -372,6 +372,11 @@ typedef struct stfem_stokes_ctx stfem_stokes_ctx; /* replaces MatrixFree + Stoke
 /* StokesMatrixFreeOperator ctor (operators.h:1200-1251); only velocity_degree == 2 is built */
 int stfem_stokes_create(const stfem_mesh_desc *mesh, int velocity_degree, double viscosity,
                         stfem_stokes_ctx **out);
+/* the same with the pressure space chosen as tests/tp_03stokes.cc:83-86 does with dGPressure: 0 = FE_Q(degree - 1) (continuous,
+ * BASELINE configs[4]), 1 = FE_DGP(degree - 1), the reference's default in tests/json/stokes.json: discontinuous, deal.II's basis
+ * of orthonormal Legendre polynomials on the reference cell (degree 1: 1, l(xi), l(eta), l(zeta), l(x) = sqrt 3 (2 x - 1)), four
+ * DoFs per cell numbered cell by cell (p[4 cell + j], cells lexicographic) */
+int stfem_stokes_create_ex(const stfem_mesh_desc *mesh, int velocity_degree, int pressure_space, double viscosity, stfem_stokes_ctx **out);
 void stfem_stokes_destroy(stfem_stokes_ctx *ctx);
 int64_t stfem_stokes_n_velocity_dofs(const stfem_stokes_ctx *ctx); /* per component */
 int64_t stfem_stokes_n_pressure_dofs(const stfem_stokes_ctx *ctx);

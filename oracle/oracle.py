@@ -64,6 +64,9 @@ def lib():
         L.stfo_stokes_n_pressure.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.stfo_stokes_apply.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int]
+        L.stfo_stokes_set_pressure_space.argtypes = [C.c_int]
+        L.stfo_stokes_n_pressure_space.restype = C.c_long
+        L.stfo_stokes_n_pressure_space.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
         L.stfo_stokes_n_face_points.restype = C.c_long
         L.stfo_stokes_n_face_points.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
         L.stfo_stokes_face_points.argtypes = [C.POINTER(C.c_int), _dp, C.c_int, C.c_int, _dp]
@@ -229,16 +232,18 @@ class StokesOracle:
     the reference's structure (operators.h:825-867: K.vmult, scatter with Alpha, M.vmult, scatter
     with Beta, one source time dof after the other)."""
 
-    def __init__(self, ncell, vertices, dirichlet_mask, viscosity, pu=2, weak_mask=0, penalty1=20.0, penalty2=10.0):
+    def __init__(self, ncell, vertices, dirichlet_mask, viscosity, pu=2, weak_mask=0, penalty1=20.0, penalty2=10.0, dg_pressure=False):
         self.nc = (C.c_int * 3)(*ncell)
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1)
         self.mask, self.nu, self.pu = int(dirichlet_mask), float(viscosity), pu
         # weak (Nitsche) boundary faces, operators.h:1206-1211, 1220-1221: gamma1 = nu penalty1, gamma2 = penalty2
         self.weak, self.penalty1, self.penalty2 = int(weak_mask), float(penalty1), float(penalty2)
+        self.pspace = 1 if dg_pressure else 0  # FE_DGP(pu - 1) instead of FE_Q(pu - 1): tests/tp_03stokes.cc:83-86
         self.n_u = lib().stfo_stokes_n_velocity(self.nc, pu)
-        self.n_p = lib().stfo_stokes_n_pressure(self.nc, pu)
+        self.n_p = lib().stfo_stokes_n_pressure_space(self.nc, pu, self.pspace)
 
     def apply(self, U, P, wK=1.0, wM=0.0):
+        lib().stfo_stokes_set_pressure_space(self.pspace)
         U = np.ascontiguousarray(U, dtype=np.float64).reshape(3 * self.n_u)
         P = np.ascontiguousarray(P, dtype=np.float64).reshape(self.n_p)
         ou = np.zeros(3 * self.n_u); op = np.zeros(self.n_p)
@@ -259,6 +264,7 @@ class StokesOracle:
 
     def nitsche_rhs(self, g_at_face_points):
         """StokesNitscheMatrixFreeOperator::vmult (operators.h:1833-1849, 1898-1940) for the Dirichlet data at face_points()"""
+        lib().stfo_stokes_set_pressure_space(self.pspace)
         g = np.ascontiguousarray(g_at_face_points, dtype=np.float64)
         ou = np.zeros(3 * self.n_u); op = np.zeros(self.n_p)
         assert lib().stfo_stokes_nitsche_rhs(self.nc, _p(self.vertices), self.pu, self.mask, self.weak, self.nu, self.penalty1,
@@ -287,6 +293,33 @@ class StokesOracle:
                 for jt in range(n_timesteps):
                     for jd in range(nt):
                         j = idx(jt, 0, jd)
+                        if abs(Beta[j, i]) > eps10:
+                            dst[j] += Beta[j, i] * mu.reshape(-1)
+        return dst
+
+    def st_Tvmult(self, Alpha, Beta, n_timesteps, n_timedofs, blocks, variable_major=True):
+        """SystemMatrixStokes::Tvmult as the reference has it (operators.h:708-745): the nine-argument scatter overload
+        (operators.h:111-123) reads  j = index(it, v, id), i = index(jt, v, jd), so every source time dof (it, id) only feeds the
+        destination blocks of ITS OWN time dof, weighted with entries of row j summed over (jt, jd) - not a transpose."""
+        nt = n_timedofs
+        idx = lambda it, v, d: stokes_block_index(nt, it, v, d, 2, variable_major)  # noqa: E731
+        eps10 = 10 * np.finfo(np.float64).eps
+        dst = [np.zeros_like(np.asarray(b, dtype=np.float64).reshape(-1)) for b in blocks]
+        for it in range(n_timesteps):
+            for d in range(nt):
+                u = np.asarray(blocks[idx(it, 0, d)]).reshape(3, self.n_u)
+                p = np.asarray(blocks[idx(it, 1, d)]).reshape(self.n_p)
+                tu, tp = self.apply(u, p, 1.0, 0.0)
+                for jt in range(n_timesteps):
+                    for jd in range(nt):
+                        for v, t in ((0, tu.reshape(-1)), (1, tp)):
+                            j, i = idx(it, v, d), idx(jt, v, jd)
+                            if abs(Alpha[j, i]) > eps10:
+                                dst[j] += Alpha[j, i] * t
+                mu, _ = self.apply(u, np.zeros(self.n_p), 0.0, 1.0)
+                for jt in range(n_timesteps):
+                    for jd in range(nt):
+                        j, i = idx(it, 0, d), idx(jt, 0, jd)
                         if abs(Beta[j, i]) > eps10:
                             dst[j] += Beta[j, i] * mu.reshape(-1)
         return dst

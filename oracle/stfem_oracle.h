@@ -95,6 +95,10 @@ int stfo_time_weights_wave(int type, int r, double tau, int nsteps, double *Alph
  *   out_u (+)= wK * (nu K u - B^T p) + wM * M u ;   out_p (+)= wK * (div u, q)          */
 long stfo_stokes_n_velocity(const int ncell[3], int pu); /* per component */
 long stfo_stokes_n_pressure(const int ncell[3], int pu);
+/* pressure space of all stfo_stokes_* calls that follow: 0 = FE_Q(pu - 1) (default), 1 = FE_DGP(pu - 1) - the reference's
+ * dGPressure (tests/tp_03stokes.cc:83-86): Legendre basis on the reference cell, DoFs cell by cell */
+void stfo_stokes_set_pressure_space(int pspace);
+long stfo_stokes_n_pressure_space(const int ncell[3], int pu, int pspace);
 int stfo_stokes_apply(const int ncell[3], const double *vertices, int pu, int dirichlet_mask,
                       double nu, double wK, double wM, const double *u, const double *p,
                       double *out_u, double *out_p, int add);

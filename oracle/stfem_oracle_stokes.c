@@ -16,7 +16,9 @@
  *        outflow faces contribute nothing in the linear case (bfp carries a factor 0.0, dn = 0);
  *   include/operators.h:1898-1940  StokesNitscheMatrixFreeOperator::do_boundary_integral_range (the Dirichlet data g).
  * Not restated: the CIP interior-face term (delta0 != 0, 1603-1638; nonlinear in the velocity) and the convection modes.
- * Velocity: FE_Q(pu)^3, pressure: FE_Q(pu-1), QGauss(pu+1), MappingQ1, homogeneous Dirichlet
+ * Velocity: FE_Q(pu)^3, pressure: FE_Q(pu-1) or (pspace = 1) FE_DGP(pu-1) as tests/tp_03stokes.cc:83-86 selects it with
+ * dGPressure (deal.II's basis: the Legendre polynomials on [0,1], orthonormal, complete degree pu-1, ordered x fastest:
+ * for pu = 2: 1, sqrt 3 (2 xi - 1), sqrt 3 (2 eta - 1), sqrt 3 (2 zeta - 1); DoFs cell by cell), QGauss(pu+1), MappingQ1, homogeneous Dirichlet
  * constraints on the velocity only.  DoF layout: velocity = 3 component arrays of the scalar
  * FE_Q(pu) numbering (component-major), pressure = scalar FE_Q(pu-1) numbering, lexicographic.
  * Parity: pinned by an independent dense numpy assembly (tests/golden/make_golden.py); the
@@ -74,6 +76,37 @@ long stfo_stokes_n_pressure(const int nc[3], int pu)
   return (long)(pp * nc[0] + 1) * (pp * nc[1] + 1) * (pp * nc[2] + 1);
 }
 
+/* ---- pressure space: 0 = FE_Q(pu - 1) (continuous, nodal), 1 = FE_DGP(pu - 1) (discontinuous, Legendre basis per cell) ---- */
+static int g_pspace = 0;
+void stfo_stokes_set_pressure_space(int pspace) { g_pspace = pspace; }
+static int dgp_n(int pp) { return (pp + 1) * (pp + 2) * (pp + 3) / 6; }
+long stfo_stokes_n_pressure_space(const int nc[3], int pu, int pspace)
+{
+  if (!pspace) return stfo_stokes_n_pressure(nc, pu);
+  return (long)nc[0] * nc[1] * nc[2] * dgp_n(pu - 1);
+}
+/* orthonormal Legendre polynomial of degree n on [0, 1] */
+static double legendre01(int n, double x)
+{
+  const double t = 2 * x - 1;
+  double p0 = 1, p1 = t;
+  if (n == 0) return 1.0;
+  for (int k = 2; k <= n; ++k) {
+    const double pk = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+    p0 = p1; p1 = pk;
+  }
+  return sqrt(2.0 * n + 1.0) * p1;
+}
+/* values of the FE_DGP(pp) basis at a reference point: PolynomialSpace order (total degree <= pp, x index fastest) */
+static int dgp_values(int pp, double x, double y, double z, double *out)
+{
+  int n = 0;
+  for (int k = 0; k <= pp; ++k)
+    for (int j = 0; j + k <= pp; ++j)
+      for (int i = 0; i + j + k <= pp; ++i) out[n++] = legendre01(i, x) * legendre01(j, y) * legendre01(k, z);
+  return n;
+}
+
 /* out_u (+)= wK * (nu K u - B^T p) + wM * M u ;  out_p (+)= wK * B u      (B u = (div u, q))
  * u, out_u: 3 * Nu doubles (component-major); p, out_p: Np doubles. */
 int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int dirichlet_mask, double nu,
@@ -84,7 +117,8 @@ int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int diric
   const int pp = pu - 1, nu1 = pu + 1, np1 = pp + 1, nq = pu + 1;
   const int ndu[3] = {pu * nc[0] + 1, pu * nc[1] + 1, pu * nc[2] + 1};
   const int ndp[3] = {pp * nc[0] + 1, pp * nc[1] + 1, pp * nc[2] + 1};
-  const long Nu = (long)ndu[0] * ndu[1] * ndu[2], Np = (long)ndp[0] * ndp[1] * ndp[2];
+  const long Nu = (long)ndu[0] * ndu[1] * ndu[2], Np = stfo_stokes_n_pressure_space(nc, pu, g_pspace);
+  const int ndg = dgp_n(pp);
   double xq[MAXN], wq[MAXN], Su[MAXN * MAXN], Du[MAXN * MAXN], Sp[MAXN * MAXN], Dp[MAXN * MAXN];
   stfo_gauss(nq, xq, wq);
   stfo_shape_tables(pu, nq, Su, Du); /* S[q*(pu+1)+a] */
@@ -94,9 +128,10 @@ int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int diric
     memset(out_p, 0, sizeof(double) * Np);
   }
   const int nvx = nc[0] + 1, nvy = nc[1] + 1;
-  const int nun = nu1 * nu1 * nu1, npn = np1 * np1 * np1, nqq = nq * nq * nq;
+  const int nun = nu1 * nu1 * nu1, npn = g_pspace ? ndg : np1 * np1 * np1, nqq = nq * nq * nq;
   double *ul = malloc(sizeof(double) * 3 * nun), *pl = malloc(sizeof(double) * npn);
   double *ru = malloc(sizeof(double) * 3 * nun), *rp = malloc(sizeof(double) * npn);
+  double pb[64];
   for (int cz = 0; cz < nc[2]; ++cz)
     for (int cy = 0; cy < nc[1]; ++cy)
       for (int cx = 0; cx < nc[0]; ++cx) {
@@ -117,6 +152,10 @@ int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int diric
               const long g = ix + (long)ndu[0] * (iy + (long)ndu[1] * iz);
               for (int comp = 0; comp < 3; ++comp) ul[comp * nun + a + nu1 * (b + nu1 * c)] = con ? 0.0 : u[comp * Nu + g];
             }
+        if (g_pspace) {
+          const long cell = cx + (long)nc[0] * (cy + (long)nc[1] * cz);
+          for (int j = 0; j < ndg; ++j) pl[j] = p[cell * ndg + j];
+        } else
         for (int c = 0; c < np1; ++c)
           for (int b = 0; b < np1; ++b)
             for (int a = 0; a < np1; ++a)
@@ -143,6 +182,10 @@ int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int diric
                   uval[comp] += w * val;
                 }
               }
+          if (g_pspace) {
+            dgp_values(pp, xq[qx], xq[qy], xq[qz], pb);
+            for (int j = 0; j < ndg; ++j) pval += pl[j] * pb[j];
+          } else
           for (int c = 0; c < np1; ++c)
             for (int b = 0; b < np1; ++b)
               for (int a = 0; a < np1; ++a)
@@ -174,6 +217,9 @@ int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int diric
                   ru[comp * nun + n] += dx * Fref[comp][0] + dy * Fref[comp][1] + dz * Fref[comp][2] +
                                         wM * val * uval[comp] * JxW;
               }
+          if (g_pspace) {
+            for (int j = 0; j < ndg; ++j) rp[j] += pb[j] * dq;
+          } else
           for (int c = 0; c < np1; ++c)
             for (int b = 0; b < np1; ++b)
               for (int a = 0; a < np1; ++a)
@@ -191,6 +237,10 @@ int stfo_stokes_apply(const int nc[3], const double *vertices, int pu, int diric
               const long g = ix + (long)ndu[0] * (iy + (long)ndu[1] * iz);
               for (int comp = 0; comp < 3; ++comp) out_u[comp * Nu + g] += ru[comp * nun + a + nu1 * (b + nu1 * c)];
             }
+        if (g_pspace) {
+          const long cell = cx + (long)nc[0] * (cy + (long)nc[1] * cz);
+          for (int j = 0; j < ndg; ++j) out_p[cell * ndg + j] += rp[j];
+        } else
         for (int c = 0; c < np1; ++c)
           for (int b = 0; b < np1; ++b)
             for (int a = 0; a < np1; ++a)
@@ -279,9 +329,11 @@ static int boundary_loop(int mode, const int nc[3], const double *vertices, int 
   stfo_shape_tables_at(pu, 2, ends, Eu, EDu);
   stfo_shape_tables_at(pp, 2, ends, Ep, EDp);
   const int nvx = nc[0] + 1, nvy = nc[1] + 1;
-  const int nun = nu1 * nu1 * nu1, npn = np1 * np1 * np1;
+  const int ndg = dgp_n(pp);
+  const int nun = nu1 * nu1 * nu1, npn = g_pspace ? ndg : np1 * np1 * np1;
   double *ul = malloc(sizeof(double) * 3 * nun), *pl = malloc(sizeof(double) * npn);
   double *ru = malloc(sizeof(double) * 3 * nun), *rp = malloc(sizeof(double) * npn);
+  double pb[64];
   face_point fp[MAXN * MAXN];
   long pt = 0;
   for (int f = 0; f < 6; ++f) {
@@ -313,6 +365,10 @@ static int boundary_loop(int mode, const int nc[3], const double *vertices, int 
                 for (int comp = 0; comp < 3; ++comp)
                   ul[comp * nun + a + nu1 * (b + nu1 * c)] = is_con(dirichlet_mask, ndu, ix, iy, iz) ? 0.0 : u[comp * Nu + gi];
               }
+          if (g_pspace) {
+            const long cell = cx + (long)nc[0] * (cy + (long)nc[1] * cz);
+            for (int j = 0; j < ndg; ++j) pl[j] = p[cell * ndg + j];
+          } else
           for (int c = 0; c < np1; ++c)
             for (int b = 0; b < np1; ++b)
               for (int a = 0; a < np1; ++a)
@@ -329,6 +385,11 @@ static int boundary_loop(int mode, const int nc[3], const double *vertices, int 
             SU[t1] = Su + q1 * nu1; DU[t1] = Du + q1 * nu1; SP[t1] = Sp + q1 * np1;
             SU[t2] = Su + q2 * nu1; DU[t2] = Du + q2 * nu1; SP[t2] = Sp + q2 * np1;
             double val[3] = {0, 0, 0}, nd[3] = {0, 0, 0}, pq = 0;
+            if (g_pspace) { /* the DGP basis at this face point (reference coordinates) */
+              double xi[3];
+              xi[d] = s; xi[t1] = xq[q1]; xi[t2] = xq[q2];
+              dgp_values(pp, xi[0], xi[1], xi[2], pb);
+            }
             if (mode == 1) {
               double gref[3][3] = {{0}}, uval[3] = {0, 0, 0}, pval = 0;
               for (int c = 0; c < nu1; ++c)
@@ -343,6 +404,9 @@ static int boundary_loop(int mode, const int nc[3], const double *vertices, int 
                       uval[comp] += w * sx * sy * sz;
                     }
                   }
+              if (g_pspace) {
+                for (int j = 0; j < ndg; ++j) pval += pl[j] * pb[j];
+              } else
               for (int c = 0; c < np1; ++c)
                 for (int b = 0; b < np1; ++b)
                   for (int a = 0; a < np1; ++a) pval += pl[a + np1 * (b + np1 * c)] * SP[0][a] * SP[1][b] * SP[2][c];
@@ -382,6 +446,9 @@ static int boundary_loop(int mode, const int nc[3], const double *vertices, int 
                   for (int k = 0; k < 3; ++k) dn += (gr[0] * P->Ji[0][k] + gr[1] * P->Ji[1][k] + gr[2] * P->Ji[2][k]) * P->n[k];
                   for (int comp = 0; comp < 3; ++comp) ru[comp * nun + n] += sx * sy * sz * val[comp] + dn * nd[comp];
                 }
+            if (g_pspace) {
+              for (int j = 0; j < ndg; ++j) rp[j] += pb[j] * pq;
+            } else
             for (int c = 0; c < np1; ++c)
               for (int b = 0; b < np1; ++b)
                 for (int a = 0; a < np1; ++a) rp[a + np1 * (b + np1 * c)] += SP[0][a] * SP[1][b] * SP[2][c] * pq;
@@ -394,6 +461,10 @@ static int boundary_loop(int mode, const int nc[3], const double *vertices, int 
               const long gi = ix + (long)ndu[0] * (iy + (long)ndu[1] * iz);
               for (int comp = 0; comp < 3; ++comp) out_u[comp * Nu + gi] += ru[comp * nun + a + nu1 * (b + nu1 * c)];
             }
+        if (g_pspace) {
+          const long cell = cx + (long)nc[0] * (cy + (long)nc[1] * cz);
+          for (int j = 0; j < ndg; ++j) out_p[cell * ndg + j] += rp[j];
+        } else
         for (int c = 0; c < np1; ++c)
           for (int b = 0; b < np1; ++b)
             for (int a = 0; a < np1; ++a)

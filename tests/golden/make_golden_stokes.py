@@ -37,7 +37,21 @@ def tables3d(p, xq):
     return N, dN
 
 
-def dense_stokes(pu, ncell, vertices, mask):
+def dgp_values(pp, X, Y, Z):
+    """FE_DGP(pp) on the reference cell as deal.II builds it (PolynomialSpace of the orthonormal Legendre polynomials on [0, 1],
+    complete degree pp, x index fastest): values [point, basis function]"""
+    def leg(n, x):
+        t = 2 * x - 1
+        return np.sqrt(2 * n + 1) * np.polynomial.legendre.legval(t, [0] * n + [1])
+    cols = []
+    for k in range(pp + 1):
+        for j in range(pp + 1 - k):
+            for i in range(pp + 1 - k - j):
+                cols.append(leg(i, X) * leg(j, Y) * leg(k, Z))
+    return np.stack(cols, axis=1)
+
+
+def dense_stokes(pu, ncell, vertices, mask, dgp=False):
     pp = pu - 1
     nq = pu + 1
     xq, wq = gauss01(nq)
@@ -48,6 +62,9 @@ def dense_stokes(pu, ncell, vertices, mask):
     ndu = [pu * n + 1 for n in ncell]
     ndp = [pp * n + 1 for n in ncell]
     NU, NP = int(np.prod(ndu)), int(np.prod(ndp))
+    if dgp:  # discontinuous pressure: the cell's own functions
+        Np_ = dgp_values(pp, QX, QY, QZ)
+        NP = int(np.prod(ncell)) * Np_.shape[1]
     K = np.zeros((NU, NU)); M = np.zeros((NU, NU)); B = np.zeros((3, NP, NU))
     nvx, nvy = ncell[0] + 1, ncell[1] + 1
     verts = vertices.reshape(-1, 3)
@@ -76,6 +93,8 @@ def dense_stokes(pu, ncell, vertices, mask):
                                for c in range(pu + 1) for b in range(pu + 1) for a in range(pu + 1)])
                 ip = np.array([(pp * cx + a) + ndp[0] * ((pp * cy + b) + ndp[1] * (pp * cz + c))
                                for c in range(pp + 1) for b in range(pp + 1) for a in range(pp + 1)])
+                if dgp:
+                    ip = (cx + ncell[0] * (cy + ncell[1] * cz)) * Np_.shape[1] + np.arange(Np_.shape[1])
                 K[np.ix_(iu, iu)] += Ke
                 M[np.ix_(iu, iu)] += Me
                 for d in range(3):
@@ -107,7 +126,7 @@ def face_tables(p, pts):
     return N, dN
 
 
-def dense_nitsche(pu, ncell, vertices, mask, weak, nu, penalty1, penalty2, gfun):
+def dense_nitsche(pu, ncell, vertices, mask, weak, nu, penalty1, penalty2, gfun, dgp=False):
     """Weak (Nitsche) boundary faces of the linear Stokes operator, reference include/operators.h:1713-1741:
          a_F((u,p),(v,q)) = int_F  -nu (grad u n).v + p n.v + gamma1/h u.v + gamma2/h (u.n)(v.n) - nu u.(grad v n) - q u.n
        with gamma1 = nu penalty1, gamma2 = penalty2, h = sqrt(area of the face)  (operators.h:184-209, 1220-1221)
@@ -117,6 +136,8 @@ def dense_nitsche(pu, ncell, vertices, mask, weak, nu, penalty1, penalty2, gfun)
     xq, wq = gauss01(nq)
     ndu = [pu * n + 1 for n in ncell]; ndp = [pp * n + 1 for n in ncell]
     NU, NP = int(np.prod(ndu)), int(np.prod(ndp))
+    if dgp:
+        NP = int(np.prod(ncell)) * ((pp + 1) * (pp + 2) * (pp + 3) // 6)
     Auu = np.zeros((3 * NU, 3 * NU)); Aup = np.zeros((3 * NU, NP)); Apu = np.zeros((NP, 3 * NU))
     Fu = np.zeros(3 * NU); Fp = np.zeros(NP)
     g1, g2 = nu * penalty1, penalty2
@@ -135,6 +156,8 @@ def dense_nitsche(pu, ncell, vertices, mask, weak, nu, penalty1, penalty2, gfun)
         Wf = np.einsum("b,a->ba", wq, wq).reshape(-1)  # q = q1 + nq q2 (the point tables run x fastest: t1 < t2)
         grid = np.meshgrid(*[np.asarray(pts[2]), np.asarray(pts[1]), np.asarray(pts[0])], indexing="ij")
         QZ, QY, QX = [gq.reshape(-1) for gq in grid]
+        if dgp:
+            Np_ = dgp_values(pp, QX, QY, QZ)
         for c2 in range(ncell[t2]):
             for c1 in range(ncell[t1]):
                 cc = [0, 0, 0]
@@ -168,6 +191,8 @@ def dense_nitsche(pu, ncell, vertices, mask, weak, nu, penalty1, penalty2, gfun)
                                for c in range(pu + 1) for b in range(pu + 1) for a in range(pu + 1)])
                 ip = np.array([(pp * cx + a) + ndp[0] * ((pp * cy + b) + ndp[1] * (pp * cz + c))
                                for c in range(pp + 1) for b in range(pp + 1) for a in range(pp + 1)])
+                if dgp:
+                    ip = (cx + ncell[0] * (cy + ncell[1] * cz)) * Np_.shape[1] + np.arange(Np_.shape[1])
                 NN = np.einsum("q,qa,qb->ab", JxW, Nu_, Nu_)
                 NdN = np.einsum("q,qa,qb->ab", JxW, Nu_, dn)     # v-value x normal derivative of u
                 for c in range(3):
@@ -250,6 +275,32 @@ def main():
               "B*1", np.abs(sum(B[c] @ np.ones(NU) for c in range(3))).max() if mask == 0 else "-")
 
 
+def main_dgp():
+    """FE_DGP(1) pressure (the reference's dGPressure = true, tests/tp_03stokes.cc:83-86): cell operator, Nitsche faces and the
+    functional of the Dirichlet data"""
+    gfun = lambda x: np.array([np.sin(1.3 * x[0] + 0.4 * x[1]) + x[2], np.cos(0.7 * x[1] - x[2]) * x[0], 0.5 + x[0] * x[1] - 0.3 * x[2] ** 2])  # noqa: E731
+    cases = [
+        ("stokes_dgp_cart_2x2x2", (2, 2, 2), (0, 0, 0), (1, 1.5, 0.7), 0.0, 63, 0, 1.0),
+        ("stokes_dgp_pert_2x3x2", (2, 3, 2), (0, 0, 0), (1, 1, 1), 0.15, 0b001100, 0b110011, 0.05),
+    ]
+    for (name, ncell, lo, up, jit, mask, weak, nu) in cases:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        verts = structured_vertices(ncell, lo, up, jit, seed=31)
+        K, M, B = dense_stokes(2, ncell, verts, mask, dgp=True)
+        NU, NP = K.shape[0], B.shape[1]
+        U = rng.uniform(-1, 1, size=(3, NU)); P = rng.uniform(-1, 1, size=NP)
+        ou, op, mu = stokes_apply(K, M, B, nu, U, P)
+        out = dict(ncell=np.array(ncell), vertices=verts, mask=mask, weak=weak, nu=nu, penalty1=20.0, penalty2=10.0, U=U, P=P, MU=mu)
+        if weak:
+            Auu, Aup, Apu, Fu, Fp, pts, gq = dense_nitsche(2, ncell, verts, mask, weak, nu, 20.0, 10.0, gfun, dgp=True)
+            ou = ou + (Auu @ U.reshape(-1) + Aup @ P).reshape(3, NU)
+            op = op + Apu @ U.reshape(-1)
+            out.update(FU=Fu.reshape(3, NU), FP=Fp, face_points=pts, G=gq)
+        out.update(SU=ou, SP=op)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "NU", NU, "NP", NP, "|B|", np.abs(B).max())
+
+
 def main_nitsche():
     """weak-boundary fixtures: StokesMatrixFreeOperator::vmult with Nitsche faces (LoopType::Full) and
     StokesNitscheMatrixFreeOperator::vmult for a smooth Dirichlet function"""
@@ -279,6 +330,9 @@ def main_nitsche():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "nitsche":
         main_nitsche()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dgp":
+        main_dgp()
     else:
         main()
         main_nitsche()
+        main_dgp()

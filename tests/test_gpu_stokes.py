@@ -248,3 +248,83 @@ def test_stokes_nitsche_vs_oracle(nc, distort, mask, weak, outflow, stfem):
     op.nitsche_rhs(G, fu, fp)
     ru, rp = orc.nitsche_rhs(G)
     assert rel(fu.download(), ru) < TOL and rel(fp.download(), rp) < TOL
+
+
+def test_stokes_reference_Tvmult(stfem):
+    """SystemMatrixStokes::Tvmult as the reference has it (operators.h:708-745: not a transpose, see the oracle's restatement)"""
+    from oracle import oracle
+    nc = (3, 2, 3)
+    verts = stfem.mesh_vertices(nc, distort=0.1, seed=5)
+    op = stfem.StokesMatrixFreeOperator(nc, vertices=verts, dirichlet_mask=63, viscosity=0.8)
+    orc = oracle.StokesOracle(nc, verts, 63, 0.8)
+    ns, r = 2, 2
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 16, ns)
+    nt, nb = r, 2 * r * ns
+    rng = np.random.default_rng(6)
+    blocks = [None] * nb
+    for it in range(ns):
+        for d in range(nt):
+            blocks[stfem.stokes_block_index(nt, it, 0, d)] = rng.uniform(-1, 1, 3 * orc.n_u)
+            blocks[stfem.stokes_block_index(nt, it, 1, d)] = rng.uniform(-1, 1, orc.n_p)
+    ref = orc.st_Tvmult(Alpha, Beta, ns, nt, blocks)
+    var = [0 if b.size == 3 * orc.n_u else 1 for b in blocks]
+    src = [op.initialize_dof_vector(v, b) for v, b in zip(var, blocks)]
+    dst = [op.initialize_dof_vector(v, np.full(b.size, 3.0)) for v, b in zip(var, blocks)]
+    op.st_Tvmult(Alpha, Beta, ns, nt, dst, src)
+    for j in range(nb):
+        assert np.linalg.norm(dst[j].download() - ref[j]) <= TOL * max(np.linalg.norm(ref[j]), 1.0), j
+    assert any(np.linalg.norm(ref[j]) > 0 for j in range(nb))
+
+
+# ---- FE_DGP(1) pressure: the reference's dGPressure = true (tests/tp_03stokes.cc:83-86, tests/json/stokes.json)
+@pytest.mark.parametrize("name", ["stokes_dgp_cart_2x2x2", "stokes_dgp_pert_2x3x2"])
+def test_stokes_dg_pressure_golden_fixture(name, stfem):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    weak = int(g["weak"])
+    op = stfem.StokesMatrixFreeOperator(tuple(g["ncell"]), vertices=g["vertices"], dirichlet_mask=int(g["mask"]), viscosity=float(g["nu"]),
+                                        weak_boundary_ids=_ids(weak), dg_pressure=True)
+    assert op.n_pressure == 4 * int(np.prod(g["ncell"])) == g["P"].size
+    u, p = op.initialize_dof_vector(0, g["U"]), op.initialize_dof_vector(1, g["P"])
+    ou, opr = op.initialize_dof_vector(0, np.full(3 * op.n_velocity, 7.0)), op.initialize_dof_vector(1, np.full(op.n_pressure, -3.0))
+    op.vmult(ou, opr, u, p)
+    assert rel(ou.download(), g["SU"]) < TOL and rel(opr.download(), g["SP"]) < TOL
+    mu = op.initialize_dof_vector(0)
+    op.mass_vmult(mu, u)
+    assert rel(mu.download(), g["MU"]) < TOL
+    if weak:
+        fu, fp = op.initialize_dof_vector(0), op.initialize_dof_vector(1)
+        op.nitsche_rhs(g["G"], fu, fp)
+        assert rel(fu.download(), g["FU"]) < TOL and rel(fp.download(), g["FP"]) < TOL
+
+
+@pytest.mark.parametrize("nc,distort,mask,weak", [((5, 4, 6), 0.15, 63, 0), ((4, 3, 5), 0.1, 0b110000, 0b001111), ((6, 2, 3), 0.0, 0, 0b111111)])
+def test_stokes_dg_pressure_vs_oracle(nc, distort, mask, weak, stfem):
+    """Q2 / P1disc against the oracle: operator (with weak faces), space-time scatter (fused: 2 time dofs; unfused: 6)"""
+    from oracle import oracle
+    nu = 0.6
+    verts = stfem.mesh_vertices(nc, distort=distort, seed=11) if distort else stfem.mesh_vertices(nc)
+    op = stfem.StokesMatrixFreeOperator(nc, vertices=verts if distort else None, dirichlet_mask=mask, viscosity=nu, weak_boundary_ids=_ids(weak),
+                                        dg_pressure=True)
+    orc = oracle.StokesOracle(nc, verts, mask, nu, weak_mask=weak, dg_pressure=True)
+    assert (op.n_velocity, op.n_pressure) == (orc.n_u, orc.n_p)
+    rng = np.random.default_rng(2)
+    U, Pp = rng.uniform(-1, 1, 3 * orc.n_u), rng.uniform(-1, 1, orc.n_p)
+    ku, kp = orc.apply(U, Pp)
+    ou, opr = op.initialize_dof_vector(0), op.initialize_dof_vector(1)
+    op.vmult(ou, opr, op.initialize_dof_vector(0, U), op.initialize_dof_vector(1, Pp))
+    assert rel(ou.download(), ku) < TOL and rel(opr.download(), kp) < TOL
+    for ns, r in ((1, 2), (2, 3)):
+        Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 16, ns)
+        nt, nb = r, 2 * r * ns
+        blocks = [None] * nb
+        for it in range(ns):
+            for d in range(nt):
+                blocks[stfem.stokes_block_index(nt, it, 0, d)] = rng.uniform(-1, 1, 3 * orc.n_u)
+                blocks[stfem.stokes_block_index(nt, it, 1, d)] = rng.uniform(-1, 1, orc.n_p)
+        ref = orc.st_vmult(Alpha, Beta, ns, nt, blocks, True)
+        var = [0 if b.size == 3 * orc.n_u else 1 for b in blocks]
+        src = [op.initialize_dof_vector(v, b) for v, b in zip(var, blocks)]
+        dst = [op.initialize_dof_vector(v, np.full(b.size, 11.0)) for v, b in zip(var, blocks)]
+        op.st_vmult(Alpha, Beta, ns, nt, dst, src, True)
+        for j in range(nb):
+            assert rel(dst[j].download(), ref[j]) < TOL, (ns, r, j)

@@ -133,3 +133,19 @@ def test_stokes_oracle_nitsche_faces_vs_dense_fixture(name, oracle_mod, golden_d
     assert np.abs(o.face_points() - g["face_points"]).max() < 1e-14
     fu, fp = o.nitsche_rhs(g["G"])
     assert rel(fu, g["FU"]) < 1e-13 and rel(fp, g["FP"]) < 1e-13
+
+
+@pytest.mark.parametrize("name", ["stokes_dgp_cart_2x2x2", "stokes_dgp_pert_2x3x2"])
+def test_stokes_oracle_dg_pressure_vs_dense_fixture(name, oracle_mod, golden_dir):
+    """FE_DGP(1) pressure (the reference's dGPressure) in the Stokes oracle - cell loop, Nitsche faces, Dirichlet functional -
+    against the independent dense numpy assembly with deal.II's Legendre basis"""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    o = oracle_mod.StokesOracle(tuple(g["ncell"]), g["vertices"], int(g["mask"]), float(g["nu"]), weak_mask=int(g["weak"]), dg_pressure=True)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    ou, op = o.apply(g["U"], g["P"])
+    assert rel(ou, g["SU"]) < 1e-13 and rel(op, g["SP"]) < 1e-13
+    mu, _ = o.apply(g["U"], g["P"], 0.0, 1.0)
+    assert rel(mu, g["MU"]) < 1e-13
+    if int(g["weak"]):
+        fu, fp = o.nitsche_rhs(g["G"])
+        assert rel(fu, g["FU"]) < 1e-13 and rel(fp, g["FP"]) < 1e-13
