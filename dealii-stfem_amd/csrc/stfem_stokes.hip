@@ -89,14 +89,16 @@ __device__ __forceinline__ void wave_fence()
 // The lane's rows / columns of the 1D tables stay in registers for the whole kernel.
 // CART: axis-aligned uniform cells (the context was created without vertices): constant diagonal Jacobian.
 // FUSED: several sources per cell, weighted sums in registers, one scatter (prm.nsrc > 1; see StokesParams)
-template <bool CART, bool FUSED>
+// PDG: FE_DGP(1) pressure (a template parameter: the FE_Q(1) instantiations stay what they were)
+template <bool CART, bool FUSED, bool PDG>
 __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm)
 {
   constexpr int RX = 351, RY = 351; // doubles per cell of the two regions (largest stage: 13 x 27)
   __shared__ double smem[8 * (RX + RY)];
-  __shared__ double tS[9], tD[9], tP[6]; // 1D tables [q*3+a], [q*3+a], [q*2+a]
+  __shared__ double tS[9], tD[9], tP[6], tL[3]; // 1D tables [q*3+a], [q*3+a], [q*2+a]; l at the Gauss points
   if (threadIdx.x < 9) { tS[threadIdx.x] = prm.Su[threadIdx.x]; tD[threadIdx.x] = prm.Du[threadIdx.x]; }
   if (threadIdx.x < 6) tP[threadIdx.x] = prm.Sp[threadIdx.x];
+  if (threadIdx.x < 3) tL[threadIdx.x] = prm.l1q[threadIdx.x];
   __syncthreads();
   const int slot = threadIdx.x >> 5, t32 = threadIdx.x & 31;
   const bool lane27 = t32 < 27;
@@ -119,9 +121,9 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   for (int n = 0; n < 2; ++n) { Pa[n] = tP[a * 2 + n]; Pb[n] = tP[b * 2 + n]; Pc[n] = tP[c * 2 + n]; }
   const double wabc = prm.wq[a] * prm.wq[b] * prm.wq[c];
   // this lane also carries a pressure DoF of the cell: FE_Q(1) node (a, b, c), or FE_DGP(1) function t
-  const bool pnode = prm.pdg ? t32 < 4 : (lane27 && a < 2 && b < 2 && c < 2);
-  const int pslot = prm.pdg ? t32 : a + 2 * b + 4 * c; // its slot in the cell's pressure values X[81 ..]
-  const double la = prm.l1q[a], lb = prm.l1q[b], lc = prm.l1q[c]; // DGP: the linear functions at this lane's quadrature point
+  const bool pnode = PDG ? t32 < 4 : (lane27 && a < 2 && b < 2 && c < 2);
+  const int pslot = PDG ? t32 : a + 2 * b + 4 * c; // its slot in the cell's pressure values X[81 ..]
+  const double la = PDG ? tL[a] : 0.0, lb = PDG ? tL[b] : 0.0, lc = PDG ? tL[c] : 0.0; // DGP: the linear functions at this lane's quadrature point
   // the cells of one colour share no DoF: the eight colours run as eight launches, lowest first, and
   // scatter with plain loads and stores (no atomics, no zeroing of the destinations, deterministic)
   const int px = prm.colour & 1, py = (prm.colour >> 1) & 1, pz = prm.colour >> 2;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     const int ix = 2 * q.cx + a, iy = 2 * q.cy + b, iz = 2 * q.cz + c;
     q.con = constrained_u(prm, ix, iy, iz);
     q.gu = ix + (long long)prm.ndu[0] * (iy + (long long)prm.ndu[1] * iz);
-    q.gp = prm.pdg ? (q.cx + (long long)prm.ncx * (q.cy + (long long)prm.ncy * q.cz)) * 4 + (t32 & 3)
+    q.gp = PDG ? (q.cx + (long long)prm.ncx * (q.cy + (long long)prm.ncy * q.cz)) * 4 + (t32 & 3)
                    : (q.cx + a1) + (long long)prm.ndp[0] * ((q.cy + b1) + (long long)prm.ndp[1] * (q.cz + c1));
     return q;
   };
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     fetch(nxt, int((it2 + 1) % nsrc));
     wave_fence();
     double pdgv[4] = {0, 0, 0, 0};
-    if (prm.pdg) {
+    if (PDG) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) pdgv[j] = X[81 + j];
     }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       gref[comp][2] = fma(Dc[2], v2, fma(Dc[1], v1, Dc[0] * v0));
     }
     double pval = fma(Pc[1], X[243 + a + 3 * b + 9], Pc[0] * X[243 + a + 3 * b]);
-    if (prm.pdg) pval = pdgv[0] + la * pdgv[1] + lb * pdgv[2] + lc * pdgv[3];
+    if (PDG) pval = pdgv[0] + la * pdgv[1] + lb * pdgv[2] + lc * pdgv[3];
 
     // ---- quadrature-point operation (operators.h:1547-1553, 1570; weights applied at scatter time) -> Y
     if (CART) {
@@ -298,11 +300,11 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
     }
     wave_fence();
     double rPdg = 0.0;
-    if (prm.pdg && t32 < 4) { // (q_j, div u): the cell's own four test functions, summed over the 27 quadrature points
+    if (PDG && t32 < 4) { // (q_j, div u): the cell's own four test functions, summed over the 27 quadrature points
       const double *fd = Y + 9 * 27;
       for (int q = 0; q < 27; ++q) {
         const int qa = q % 3, qb = (q / 3) % 3, qc = q / 9;
-        const double l = t32 == 0 ? 1.0 : prm.l1q[t32 == 1 ? qa : (t32 == 2 ? qb : qc)];
+        const double l = t32 == 0 ? 1.0 : tL[t32 == 1 ? qa : (t32 == 2 ? qb : qc)];
         rPdg = fma(l, fd[q], rPdg);
       }
     }
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       rM[comp] = fma(SaT[2], hm[2], fma(SaT[1], hm[1], SaT[0] * hm[0]));
     }
     const double *hd = Y + 243 + 3 * b + 9 * c;
-    const double rP = prm.pdg ? rPdg : fma(PaT[2], hd[2], fma(PaT[1], hd[1], PaT[0] * hd[0]));
+    const double rP = PDG ? rPdg : fma(PaT[2], hd[2], fma(PaT[1], hd[1], PaT[0] * hd[0]));
 
     // ---- distribute_local_to_global: constrained velocity rows stay 0.  A DoF on a face shared with a
     // neighbouring cell is first touched by the cell whose colour bits are 0 in all shared directions.
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
       const bool fu = !((a == 0 && cx > 0 && px) || (a == 2 && cx < prm.ncx - 1 && px) ||
                         (b == 0 && cy > 0 && py) || (b == 2 && cy < prm.ncy - 1 && py) ||
                         (c == 0 && cz > 0 && pz) || (c == 2 && cz < prm.ncz - 1 && pz));
-      const bool fp = prm.pdg || !((a == 0 && cx > 0 && px) || (a == 1 && cx < prm.ncx - 1 && px) ||
+      const bool fp = PDG || !((a == 0 && cx > 0 && px) || (a == 1 && cx < prm.ncx - 1 && px) ||
                                     (b == 0 && cy > 0 && py) || (b == 1 && cy < prm.ncy - 1 && py) ||
                                     (c == 0 && cz > 0 && pz) || (c == 1 && cz < prm.ncz - 1 && pz));
       if constexpr (FUSED) {
@@ -419,6 +421,251 @@ __global__ __launch_bounds__(256) void stokes_cell_kernel(const StokesParams prm
   }
 }
 
+
+// ---- axis-aligned uniform meshes: the operator in its Kronecker form (round 3) ----
+// On boxes of identical cells the velocity part  nu K u_c + wM M u_c  of every component is the SCALAR space-time operator of
+// FE_Q(2): it runs as the scalar pencil sweep (stfem_st_vmult on a Q2 context: owner-writes, every DoF stored once), the
+// components being blocks.  What is left of the cell loop (operators.h:1547-1570) is the coupling
+//     out_u_c -= B_c^T p,   out_p = sum_c B_c u_c,   B_c = (q, d u_c / d x_c),
+// whose cell matrices are Kronecker products of 1D mixed matrices (N = int phi_a psi_j, C = int phi_a' psi_j), so both run in
+// GATHER form - one thread per destination DoF sums what its <= 8 cells contribute, in a fixed order: no colours, no atomics,
+// every destination touched once.  (Measured on 64^3 cells the eight colour launches of the cell kernel were bound by their
+// access pattern and LDS traffic: profiles/r2/stokes.)
+struct CouplingParams {
+  int ncx, ncy, ncz;
+  int ndu[3], ndp[3];
+  long long Nu;
+  int dmask, pdg;
+  double h[3];
+  // 1D reference integrals, Q2 node a: FE_Q(1): N[a][j], C[a][j], j = 0, 1; FE_DGP(1): N[a][0] = int phi_a, N[a][1] = int l phi_a (same for C)
+  double N[3][2], C[3][2];
+  int nsrc, nout;
+  const double *u[MAXSRC], *p[MAXSRC];
+  double *out_u[MAXOUT], *out_p[MAXOUT];
+  double wKu[MAXOUT][MAXSRC], wKp[MAXOUT][MAXSRC]; // [output][source]
+  int store_p[MAXOUT];
+};
+
+// FE_Q(1): the pressure nodes a velocity line node i couples to: first index p0, weights of up to three (value / derivative forms)
+__device__ __forceinline__ void q1_row(const CouplingParams &P, int i, int nc, int &p0, double (&wn)[3], double (&wc)[3])
+{
+  if (i & 1) { // midpoint of cell c
+    p0 = i >> 1;
+    wn[0] = P.N[1][0]; wn[1] = P.N[1][1]; wn[2] = 0.0;
+    wc[0] = P.C[1][0]; wc[1] = P.C[1][1]; wc[2] = 0.0;
+  } else { // vertex between cells c - 1 (its node 2) and c (its node 0)
+    const int c = i >> 1;
+    const bool lo = c > 0, hi = c < nc;
+    p0 = c - 1;
+    wn[0] = lo ? P.N[2][0] : 0.0; wn[1] = (lo ? P.N[2][1] : 0.0) + (hi ? P.N[0][0] : 0.0); wn[2] = hi ? P.N[0][1] : 0.0;
+    wc[0] = lo ? P.C[2][0] : 0.0; wc[1] = (lo ? P.C[2][1] : 0.0) + (hi ? P.C[0][0] : 0.0); wc[2] = hi ? P.C[0][1] : 0.0;
+  }
+}
+
+// out_u[o][c][node] -= sum_s wKu[o][s] (B_c^T p_s)[node]: one thread per velocity node.  NS / NO: compile-time bounds of the
+// source / destination loops (their accumulators then live in registers; with run-time bounds the generic instantiation
+// needed 246 VGPRs and scratch)
+template <int NS, int NO, bool PDG>
+__global__ __launch_bounds__(256, NO <= 2 ? 3 : 2) void stokes_grad_kernel(const CouplingParams P)
+{
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= P.Nu) return;
+  const int ix = int(node % P.ndu[0]), iy = int((node / P.ndu[0]) % P.ndu[1]), iz = int(node / ((long long)P.ndu[0] * P.ndu[1]));
+  const bool con = ((P.dmask & 1) && ix == 0) || ((P.dmask & 2) && ix == P.ndu[0] - 1) || ((P.dmask & 4) && iy == 0) ||
+                   ((P.dmask & 8) && iy == P.ndu[1] - 1) || ((P.dmask & 16) && iz == 0) || ((P.dmask & 32) && iz == P.ndu[2] - 1);
+  if (con) return; // constrained rows are not written (they hold the sweep's exact zero)
+  double acc[NO][3];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o][0] = acc[o][1] = acc[o][2] = 0.0;
+  const int nc[3] = {P.ncx, P.ncy, P.ncz};
+  const int idx[3] = {ix, iy, iz};
+  if constexpr (!PDG) {
+    int p0[3];
+    double wn[3][3], wc[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      q1_row(P, d == 0 ? ix : (d == 1 ? iy : iz), d == 0 ? P.ncx : (d == 1 ? P.ncy : P.ncz), p0[d], wn[d], wc[d]);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) wn[d][e] *= P.h[d]; // the value forms carry the cell size, the derivative forms do not
+    }
+    // entries beyond the lattice carry weight 0: clamp their index and keep the loops free of branches (27 independent loads)
+    int jx[3], jy[3], jz[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      jx[e] = min(max(p0[0] + e, 0), P.ndp[0] - 1);
+      jy[e] = min(max(p0[1] + e, 0), P.ndp[1] - 1);
+      jz[e] = min(max(p0[2] + e, 0), P.ndp[2] - 1);
+    }
+    _Pragma("unroll 1") for (int s = 0; s < P.nsrc; ++s) { // (a run-time loop: only the destination loops need compile-time bounds)
+      double g[3] = {0, 0, 0};
+      const double *ps = P.p[s];
+#pragma unroll
+      for (int ez = 0; ez < 3; ++ez) { // separable sums (no table of the 81 weight products)
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int ey = 0; ey < 3; ++ey) {
+          const double *row = ps + (long long)P.ndp[0] * (jy[ey] + (long long)P.ndp[1] * jz[ez]);
+          double sc = 0.0, sn = 0.0;
+#pragma unroll
+          for (int ex = 0; ex < 3; ++ex) {
+            const double pv = row[jx[ex]];
+            sc = fma(wc[0][ex], pv, sc);
+            sn = fma(wn[0][ex], pv, sn);
+          }
+          a0 = fma(wn[1][ey], sc, a0);
+          a1 = fma(wc[1][ey], sn, a1);
+          a2 = fma(wn[1][ey], sn, a2);
+        }
+        g[0] = fma(wn[2][ez], a0, g[0]);
+        g[1] = fma(wn[2][ez], a1, g[1]);
+        g[2] = fma(wc[2][ez], a2, g[2]);
+        __builtin_amdgcn_sched_barrier(0); // nine loads in flight at a time
+      }
+      _Pragma("unroll") for (int o = 0; o < NO; ++o)
+        if (o < P.nout)
+          for (int c = 0; c < 3; ++c) acc[o][c] = fma(P.wKu[o][s], g[c], acc[o][c]);
+    }
+  } else {
+    // FE_DGP(1): the node's cells (per direction: the cell it is node a of), four functions each
+    int c0[3], na[3], aa[3][2];
+    for (int d = 0; d < 3; ++d) {
+      if (idx[d] & 1) { c0[d] = idx[d] >> 1; na[d] = 1; aa[d][0] = 1; aa[d][1] = 1; }
+      else {
+        c0[d] = (idx[d] >> 1) - 1; // vertex: node 2 of the cell below, node 0 of the cell above
+        aa[d][0] = 2; aa[d][1] = 0;
+        na[d] = 2;
+      }
+    }
+    _Pragma("unroll 1") for (int s = 0; s < P.nsrc; ++s) { // (a run-time loop: only the destination loops need compile-time bounds)
+      double g[3] = {0, 0, 0};
+      for (int ez = 0; ez < na[2]; ++ez) {
+        const int cz = c0[2] + ez, az = aa[2][ez];
+        if (cz < 0 || cz >= P.ncz) continue;
+        for (int ey = 0; ey < na[1]; ++ey) {
+          const int cy = c0[1] + ey, ay = aa[1][ey];
+          if (cy < 0 || cy >= P.ncy) continue;
+          for (int ex = 0; ex < na[0]; ++ex) {
+            const int cx = c0[0] + ex, ax = aa[0][ex];
+            if (cx < 0 || cx >= P.ncx) continue;
+            const double *pc = P.p[s] + 4 * (cx + (long long)P.ncx * (cy + (long long)P.ncy * cz));
+            const double q0 = pc[0], q1 = pc[1], q2 = pc[2], q3 = pc[3];
+            const double Nx0 = P.h[0] * P.N[ax][0], Nx1 = P.h[0] * P.N[ax][1], Ny0 = P.h[1] * P.N[ay][0], Ny1 = P.h[1] * P.N[ay][1],
+                         Nz0 = P.h[2] * P.N[az][0], Nz1 = P.h[2] * P.N[az][1];
+            // int (q0 + q1 l(xi) + q2 l(eta) + q3 l(zeta)) d phi / d x_c
+            g[0] += (q0 * P.C[ax][0] + q1 * P.C[ax][1]) * Ny0 * Nz0 + P.C[ax][0] * (q2 * Ny1 * Nz0 + q3 * Ny0 * Nz1);
+            g[1] += (q0 * P.C[ay][0] + q2 * P.C[ay][1]) * Nx0 * Nz0 + P.C[ay][0] * (q1 * Nx1 * Nz0 + q3 * Nx0 * Nz1);
+            g[2] += (q0 * P.C[az][0] + q3 * P.C[az][1]) * Nx0 * Ny0 + P.C[az][0] * (q1 * Nx1 * Ny0 + q2 * Nx0 * Ny1);
+          }
+        }
+      }
+_Pragma("unroll") for (int o = 0; o < NO; ++o)
+        if (o < P.nout)
+          for (int c = 0; c < 3; ++c) acc[o][c] = fma(P.wKu[o][s], g[c], acc[o][c]);
+    }
+  }
+_Pragma("unroll") for (int o = 0; o < NO; ++o)
+    if (o < P.nout && P.out_u[o])
+      for (int c = 0; c < 3; ++c) P.out_u[o][c * P.Nu + node] -= acc[o][c];
+}
+
+// out_p[o] (=, +=) sum_s wKp[o][s] sum_c B_c u_s,c: one thread per pressure DoF (FE_Q(1) node / FE_DGP(1) cell function)
+// (Five threads per FE_Q(1) node, one per z-plane of its 5 x 5 x 5 neighbourhood, with the partial sums added in LDS, measured
+// slower: 79 against 62 us on 64^3 cells - the per-thread weight set-up is what one thread per node amortises.)
+template <int NS, int NO, bool PDG>
+__global__ __launch_bounds__(256, NO <= 2 ? 4 : 2) void stokes_div_kernel(const CouplingParams P, long long Np)
+{
+  const long long dof = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (dof >= Np) return;
+  const int nc[3] = {P.ncx, P.ncy, P.ncz};
+  double acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = 0.0;
+  auto con = [&](int ix, int iy, int iz) {
+    return ((P.dmask & 1) && ix == 0) || ((P.dmask & 2) && ix == P.ndu[0] - 1) || ((P.dmask & 4) && iy == 0) ||
+           ((P.dmask & 8) && iy == P.ndu[1] - 1) || ((P.dmask & 16) && iz == 0) || ((P.dmask & 32) && iz == P.ndu[2] - 1);
+  };
+  if constexpr (!PDG) {
+    const int j[3] = {int(dof % P.ndp[0]), int((dof / P.ndp[0]) % P.ndp[1]), int(dof / ((long long)P.ndp[0] * P.ndp[1]))};
+    // velocity line nodes 2 j - 2 .. 2 j + 2: (cell j - 1: nodes 0, 1, 2 against psi_1), (cell j: nodes 0, 1, 2 against psi_0)
+    double wn[3][5], wc[3][5];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool lo = j[d] > 0, hi = j[d] < nc[d];
+      wn[d][0] = lo ? P.N[0][1] : 0.0; wn[d][1] = lo ? P.N[1][1] : 0.0; wn[d][2] = (lo ? P.N[2][1] : 0.0) + (hi ? P.N[0][0] : 0.0);
+      wn[d][3] = hi ? P.N[1][0] : 0.0; wn[d][4] = hi ? P.N[2][0] : 0.0;
+      wc[d][0] = lo ? P.C[0][1] : 0.0; wc[d][1] = lo ? P.C[1][1] : 0.0; wc[d][2] = (lo ? P.C[2][1] : 0.0) + (hi ? P.C[0][0] : 0.0);
+      wc[d][3] = hi ? P.C[1][0] : 0.0; wc[d][4] = hi ? P.C[2][0] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) wn[d][k] *= P.h[d];
+    }
+    // nodes beyond the lattice and constrained nodes (they read as 0) carry weight 0: the loops are free of branches
+    const int lim[3] = {P.ndu[0] - 1, P.ndu[1] - 1, P.ndu[2] - 1};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int i = 2 * j[d] - 2 + k;
+        const bool off = i < 0 || i > lim[d] || ((P.dmask >> (2 * d) & 1) && i == 0) || ((P.dmask >> (2 * d + 1) & 1) && i == lim[d]);
+        if (off) wn[d][k] = wc[d][k] = 0.0;
+      }
+    // (the y / z loops stay rolled: their weights are picked with selects on the wave-uniform loop counters, not indexed)
+    auto pick = [](const double (&w)[5], int k) { return k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : (k == 3 ? w[3] : w[4]))); };
+    int ixs[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ixs[k] = min(max(2 * j[0] - 2 + k, 0), lim[0]);
+    _Pragma("unroll 1") for (int s = 0; s < P.nsrc; ++s) {
+      double dv = 0.0;
+      const double *us = P.u[s];
+      _Pragma("unroll 1") for (int kz = 0; kz < 5; ++kz) {
+        const int iz = min(max(2 * j[2] - 2 + kz, 0), lim[2]);
+        const double nz = pick(wn[2], kz), cz = pick(wc[2], kz);
+        _Pragma("unroll 1") for (int ky = 0; ky < 5; ++ky) {
+          const int iy = min(max(2 * j[1] - 2 + ky, 0), lim[1]);
+          const double ny = pick(wn[1], ky), cy = pick(wc[1], ky);
+          const double *row = us + (long long)P.ndu[0] * (iy + (long long)P.ndu[1] * iz);
+          double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) {
+            const double *uu = row + ixs[kx];
+            sx = fma(wc[0][kx], uu[0], sx);
+            sy = fma(wn[0][kx], uu[P.Nu], sy);
+            sz = fma(wn[0][kx], uu[2 * P.Nu], sz);
+          }
+          dv = fma(ny * nz, sx, fma(cy * nz, sy, fma(ny * cz, sz, dv)));
+        }
+      }
+      _Pragma("unroll") for (int o = 0; o < NO; ++o)
+        if (o < P.nout) acc[o] = fma(P.wKp[o][s], dv, acc[o]);
+    }
+  } else {
+    const long long cell = dof >> 2;
+    const int fn = int(dof & 3);
+    const int cx = int(cell % P.ncx), cy = int((cell / P.ncx) % P.ncy), cz = int(cell / ((long long)P.ncx * P.ncy));
+    _Pragma("unroll 1") for (int s = 0; s < P.nsrc; ++s) { // (a run-time loop: only the destination loops need compile-time bounds)
+      double dv = 0.0;
+      for (int az = 0; az < 3; ++az)
+        for (int ay = 0; ay < 3; ++ay)
+          for (int ax = 0; ax < 3; ++ax) {
+            const int ix = 2 * cx + ax, iy = 2 * cy + ay, iz = 2 * cz + az;
+            if (con(ix, iy, iz)) continue;
+            const double *uu = P.u[s] + (ix + (long long)P.ndu[0] * (iy + (long long)P.ndu[1] * iz));
+            // test function fn: 1 / l(xi) / l(eta) / l(zeta): index 1 of N / C in that direction
+            const int fx = fn == 1, fy = fn == 2, fz = fn == 3;
+            const double Nx = P.h[0] * P.N[ax][fx], Ny = P.h[1] * P.N[ay][fy], Nz = P.h[2] * P.N[az][fz];
+            dv = fma(P.C[ax][fx] * Ny * Nz, uu[0], dv);
+            dv = fma(Nx * P.C[ay][fy] * Nz, uu[P.Nu], dv);
+            dv = fma(Nx * Ny * P.C[az][fz], uu[2 * P.Nu], dv);
+          }
+      _Pragma("unroll") for (int o = 0; o < NO; ++o)
+        if (o < P.nout) acc[o] = fma(P.wKp[o][s], dv, acc[o]);
+    }
+  }
+  _Pragma("unroll") for (int o = 0; o < NO; ++o)
+    if (o < P.nout && P.out_p[o]) {
+      if (P.store_p[o]) P.out_p[o][dof] = acc[o];
+      else P.out_p[o][dof] += acc[o];
+    }
+}
 
 // ---- boundary faces of the linear operator (LoopType::Full, reference include/operators.h:1640-1741) ----
 // Weak (Nitsche) faces: v <- -nu grad u n + p n + gamma1/h u + gamma2/h n (u.n), dv/dn <- -nu u, q <- -u.n with
@@ -668,6 +915,10 @@ struct stfem_stokes_ctx {
   StokesParams base;
   // weak (Nitsche) / outflow boundary faces (operators.h:1206-1211): bit f = 2 d + s
   int pspace = 0; // 0 = FE_Q(1), 1 = FE_DGP(1)
+  // axis-aligned uniform meshes: the scalar FE_Q(2) context whose pencil sweep applies nu K + wM M to the velocity components,
+  // and the 1D tables of the coupling kernels
+  stfem_ctx *scalar = nullptr;
+  CouplingParams coupling;
   int weak_mask = 0, outflow_mask = 0;
   double penalty1 = 20.0, penalty2 = 10.0;
   BoundaryParams bnd;
@@ -783,6 +1034,36 @@ int stfem_stokes_create_ex(const stfem_mesh_desc *mesh, int velocity_degree, int
     b.hinv[d] = 1.0 / h;
     b.detJ *= h;
   }
+  std::memset(&c->coupling, 0, sizeof(c->coupling));
+  if (b.cart) {
+    const char *e = getenv("STFEM_STOKES_CELL"); // 1: keep the cell kernel on boxes too (cross-checks, measurements)
+    if (!(e && atoi(e) != 0)) {
+      stfem_mesh_desc md = *mesh;
+      md.vertices = nullptr;
+      stfem_space_desc sd{2, 3, 1, 0};
+      const int rc = stfem_ctx_create(&md, &sd, &c->scalar);
+      if (rc != STFEM_OK) c->scalar = nullptr; // (the cell kernel serves then)
+    }
+    CouplingParams &k = c->coupling;
+    k.ncx = c->nc[0]; k.ncy = c->nc[1]; k.ncz = c->nc[2];
+    for (int d = 0; d < 3; ++d) {
+      k.ndu[d] = c->ndu[d]; k.ndp[d] = c->ndp[d];
+      k.h[d] = (mesh->upper[d] - mesh->lower[d]) / c->nc[d];
+    }
+    k.Nu = c->Nu; k.dmask = c->dmask; k.pdg = c->pspace;
+    // 1D integrals on the reference cell with the operator's Gauss rule (exact for these polynomials)
+    for (int a = 0; a < 3; ++a)
+      for (int j = 0; j < 2; ++j) {
+        double n = 0.0, cc = 0.0;
+        for (int q = 0; q < 3; ++q) {
+          const double psi = c->pspace ? (j == 0 ? 1.0 : std::sqrt(3.0) * (2.0 * xq[q] - 1.0)) : Sp[q * 2 + j];
+          n += wq[q] * tu.S[q * 3 + a] * psi;
+          cc += wq[q] * tu.D[q * 3 + a] * psi;
+        }
+        k.N[a][j] = n;
+        k.C[a][j] = cc;
+      }
+  }
   *out = c;
   return STFEM_OK;
 }
@@ -793,6 +1074,7 @@ void stfem_stokes_destroy(stfem_stokes_ctx *c)
   (void)hipSetDevice(c->device);
   if (c->d_vertices) (void)hipFree(c->d_vertices);
   if (c->d_g) (void)hipFree(c->d_g);
+  if (c->scalar) stfem_ctx_destroy(c->scalar);
   delete c;
 }
 
@@ -860,9 +1142,109 @@ static int stokes_boundary_launch(stfem_stokes_ctx *c, StokesParams &prm, const 
   return STFEM_OK;
 }
 
+// The Kronecker path of stokes_launch (axis-aligned uniform meshes): the same arguments, three steps.
+static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipStream_t st)
+{
+  const int nsrc = prm.nsrc > 1 ? prm.nsrc : 1, nout = prm.nout;
+  if (nsrc > MAXSRC || nout > MAXOUT) return STFEM_ERR_UNSUPPORTED;
+  const double *us[MAXSRC], *ps[MAXSRC];
+  double wKu[MAXOUT][MAXSRC], wKp[MAXOUT][MAXSRC], wM[MAXOUT][MAXSRC];
+  for (int q = 0; q < nsrc; ++q) {
+    us[q] = prm.nsrc > 1 ? prm.us[q] : prm.u;
+    ps[q] = prm.nsrc > 1 ? prm.ps[q] : prm.p;
+    for (int o = 0; o < nout; ++o) {
+      wKu[o][q] = prm.nsrc > 1 ? prm.fKu[o][q] : prm.wKu[o];
+      wKp[o][q] = prm.nsrc > 1 ? prm.fKp[o][q] : prm.wKp[o];
+      wM[o][q] = prm.nsrc > 1 ? prm.fM[o][q] : prm.wM[o];
+    }
+  }
+  // ---- 1. velocity blocks: out_u[o] (=, +=) sum_q (nu wKu K + wM M) u_q, component by component as scalar FE_Q(2) systems
+  // (one launch with the three components as blocks when there is a single source and destination)
+  for (int pass = 0; pass < 2; ++pass) { // destinations that are overwritten, then those that are accumulated into
+    int rows[MAXOUT], nr = 0;
+    for (int o = 0; o < nout; ++o)
+      if (prm.out_u[o] && (prm.store_u[o] != 0) == (pass == 0)) rows[nr++] = o;
+    if (nr == 0) continue;
+    const int ncomp_blocks = (nr == 1 && nsrc == 1) ? 3 : 1; // components as blocks of one launch, or one launch per component
+    for (int c0 = 0; c0 < 3; c0 += ncomp_blocks) {
+      const int nbo = nr * ncomp_blocks, nbi = nsrc * ncomp_blocks;
+      std::vector<void *> dptr(nbo), sptr(nbi);
+      std::vector<double> a(size_t(nbo) * nbi, 0.0), b(size_t(nbo) * nbi, 0.0);
+      for (int cc = 0; cc < ncomp_blocks; ++cc) {
+        for (int r = 0; r < nr; ++r) dptr[cc * nr + r] = prm.out_u[rows[r]] + (c0 + cc) * c->Nu;
+        for (int q = 0; q < nsrc; ++q) sptr[cc * nsrc + q] = const_cast<double *>(us[q]) + (c0 + cc) * c->Nu;
+        for (int r = 0; r < nr; ++r)
+          for (int q = 0; q < nsrc; ++q) {
+            a[size_t(cc * nr + r) * nbi + cc * nsrc + q] = c->nu * wKu[rows[r]][q];
+            b[size_t(cc * nr + r) * nbi + cc * nsrc + q] = wM[rows[r]][q];
+          }
+      }
+      stfem_vec *vd = nullptr, *vs = nullptr;
+      int rc = stfem_vector_wrap(c->scalar, nbo, dptr.data(), &vd);
+      if (rc == STFEM_OK) rc = stfem_vector_wrap(c->scalar, nbi, sptr.data(), &vs);
+      if (rc == STFEM_OK) rc = stfem_st_vmult(c->scalar, nbo, nbi, a.data(), b.data(), 0, pass, vd, vs, st);
+      if (vd) stfem_vector_destroy(vd);
+      if (vs) stfem_vector_destroy(vs);
+      if (rc != STFEM_OK) {
+        snprintf(g_stokes_err, sizeof(g_stokes_err), "velocity sweep: status %d (%s)", rc, stfem_last_hip_error());
+        return rc;
+      }
+    }
+  }
+  // ---- 2., 3. the coupling, in gather form
+  bool k_u = false, k_p = false;
+  for (int o = 0; o < nout; ++o)
+    for (int q = 0; q < nsrc; ++q) {
+      k_u = k_u || (prm.out_u[o] && wKu[o][q] != 0.0 && ps[q]);
+      k_p = k_p || (prm.out_p[o] && wKp[o][q] != 0.0);
+    }
+  CouplingParams k = c->coupling;
+  k.nsrc = nsrc; k.nout = nout;
+  for (int q = 0; q < nsrc; ++q) { k.u[q] = us[q]; k.p[q] = ps[q]; }
+  for (int o = 0; o < nout; ++o) {
+    k.out_u[o] = prm.out_u[o]; k.out_p[o] = prm.out_p[o];
+    k.store_p[o] = prm.store_p[o];
+    for (int q = 0; q < nsrc; ++q) { k.wKu[o][q] = ps[q] ? wKu[o][q] : 0.0; k.wKp[o][q] = wKp[o][q]; }
+  }
+  (void)hipGetLastError();
+#define STOKES_COUPLING_LAUNCH(KERN, NS_, NO_, GRID, ...)                                                          \
+  do {                                                                                                             \
+    if (k.pdg) hipLaunchKernelGGL((stokes_##KERN##_kernel<NS_, NO_, true>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((stokes_##KERN##_kernel<NS_, NO_, false>), dim3(GRID), dim3(GRID##_threads), 0, st, __VA_ARGS__); \
+  } while (0)
+  const unsigned gu = (unsigned)((c->Nu + 255) / 256), gp = (unsigned)((c->Np + 255) / 256);
+  const unsigned gu_threads = 256, gp_threads = 256;
+  const int shape = (nsrc == 1 && nout == 1) ? 0 : ((nsrc <= 2 && nout <= 2) ? 1 : ((nsrc <= MAXSRC && nout <= 4) ? 2 : 3));
+  if (k_u) {
+    if (shape == 0) STOKES_COUPLING_LAUNCH(grad, 1, 1, gu, k);
+    else if (shape == 1) STOKES_COUPLING_LAUNCH(grad, 2, 2, gu, k);
+    else if (shape == 2) STOKES_COUPLING_LAUNCH(grad, MAXSRC, 4, gu, k);
+    else STOKES_COUPLING_LAUNCH(grad, MAXSRC, MAXOUT, gu, k);
+  }
+  bool any_p = false;
+  for (int o = 0; o < nout; ++o) any_p = any_p || prm.out_p[o];
+  (void)k_p; // (a destination that is overwritten is written even with zero weights)
+  if (any_p) {
+    if (shape == 0) STOKES_COUPLING_LAUNCH(div, 1, 1, gp, k, c->Np);
+    else if (shape == 1) STOKES_COUPLING_LAUNCH(div, 2, 2, gp, k, c->Np);
+    else if (shape == 2) STOKES_COUPLING_LAUNCH(div, MAXSRC, 4, gp, k, c->Np);
+    else STOKES_COUPLING_LAUNCH(div, MAXSRC, MAXOUT, gp, k, c->Np);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_stokes_err, sizeof(g_stokes_err), "stokes coupling kernels: %s", hipGetErrorString(e));
+    return STFEM_ERR_HIP;
+  }
+  return STFEM_OK;
+}
+
 static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
 {
   (void)hipGetLastError();
+  if (c->scalar && prm.nout <= MAXOUT && prm.nsrc <= MAXSRC) { // axis-aligned uniform mesh: Kronecker path
+    const int rc = stokes_cart_launch(c, prm, st);
+    if (rc != STFEM_OK) return rc;
+  } else
   for (int colour = 0; colour < 8; ++colour) { // ascending: see store_u / store_p
     const long long n = (long long)((c->nc[0] - (colour & 1) + 1) / 2) * ((c->nc[1] - ((colour >> 1) & 1) + 1) / 2) *
                         ((c->nc[2] - (colour >> 2) + 1) / 2);
@@ -874,11 +1256,15 @@ static int stokes_launch(stfem_stokes_ctx *c, StokesParams &prm, hipStream_t st)
       const char *e = getenv("STFEM_STOKES_GRID"); // workgroups per CU of a colour launch (experiments)
       return e ? std::max(1, atoi(e)) : 0;
     }();
-    const void *kern = prm.nsrc > 1 ? (prm.cart ? (const void *)stokes_cell_kernel<true, true> : (const void *)stokes_cell_kernel<false, true>)
-                                    : (prm.cart ? (const void *)stokes_cell_kernel<true, false> : (const void *)stokes_cell_kernel<false, false>);
-    // resident workgroups per CU of the four instantiations, asked once (not on the launch path)
-    static int resident_of[4] = {0, 0, 0, 0};
-    int &resident = resident_of[(prm.nsrc > 1 ? 2 : 0) + (prm.cart ? 1 : 0)];
+    const void *kerns[8] = {(const void *)stokes_cell_kernel<false, false, false>, (const void *)stokes_cell_kernel<true, false, false>,
+                            (const void *)stokes_cell_kernel<false, true, false>,  (const void *)stokes_cell_kernel<true, true, false>,
+                            (const void *)stokes_cell_kernel<false, false, true>,  (const void *)stokes_cell_kernel<true, false, true>,
+                            (const void *)stokes_cell_kernel<false, true, true>,   (const void *)stokes_cell_kernel<true, true, true>};
+    const int which = (prm.pdg ? 4 : 0) + (prm.nsrc > 1 ? 2 : 0) + (prm.cart ? 1 : 0);
+    const void *kern = kerns[which];
+    // resident workgroups per CU of the instantiations, asked once (not on the launch path)
+    static int resident_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int &resident = resident_of[which];
     if (resident < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, 256, 0) != hipSuccess || resident < 1)) resident = 2;
     const unsigned grid = (unsigned)std::min<long long>((n + 7) / 8, (long long)c->n_cu * (grid_env ? grid_env : resident));
     void *args[] = {(void *)&prm};
