@@ -699,15 +699,21 @@ template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, c
 
 // cell rows per pencil: two, except where the second set of z-carry registers makes the kernel spill
 // (Q4 with three temporal blocks; tools/check_async.py fails the build if an instantiation spills)
-constexpr int pencil_ty(int p, int nbm) { return (p == 4 && nbm == 3) ? 1 : 2; }
+// Q1 / Q2 pencils of up to four blocks take four cell rows: fewer mailbox rows and y-halo rows per cell where the work per cell group
+// is small (measured, Q2 on 144^3 cells: cG(1) x 4 steps 1.27 -> 1.16 ms, cG(2) 0.471 -> 0.443 ms; profiles/r3/experiments.txt).
+// pencil_ty: the largest instantiated value = the default; STFEM_PENCIL_TY selects a smaller instantiated one (1, 2, 4).
+constexpr int pencil_ty(int p, int nbm) { return (p == 4 && nbm == 3) ? 1 : ((p <= 2 && nbm <= 4) ? 4 : 2); }
+constexpr int pencil_ty_default(int p, int nbm) { return pencil_ty(p, nbm); }
 
 template <int P, int NBM> int launch_pencil_t(const SweepParams &prm, const PencilPlan &pp, hipStream_t st)
 {
   if constexpr (Geometry<P, NBM>::CELLS_PER_WAVE < 2) return -2; // needs the halo slot and at least one owned cell
   else {
     if (pp.ty == 1) return launch_pencil_ty<P, NBM, 1>(prm, pp, st);
-    if constexpr (pencil_ty(P, NBM) == 2)
+    if constexpr (pencil_ty(P, NBM) >= 2)
       if (pp.ty == 2) return launch_pencil_ty<P, NBM, 2>(prm, pp, st);
+    if constexpr (pencil_ty(P, NBM) >= 4)
+      if (pp.ty == 4) return launch_pencil_ty<P, NBM, 4>(prm, pp, st);
     return -2;
   }
 }
@@ -753,7 +759,7 @@ int pencil_geometry(int p, int nbm, int ty, PencilPlan &plan)
 {
   if (p < 1 || p > 4) return -2;
   nbm = round_nbm(nbm);
-  if (ty < 1 || ty > pencil_ty(p, nbm)) ty = pencil_ty(p, nbm);
+  if (ty < 1 || ty > pencil_ty(p, nbm) || ty == 3) ty = pencil_ty_default(p, nbm);
   // (four and more temporal blocks per launch: PencilCore::middle_stream; the caller cuts systems for which
   // fewer than two cells fit a wave - Q4 with seven or eight blocks - into smaller panels)
   const int cpw = (64 / (p + 1)) / nbm;
