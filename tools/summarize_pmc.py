@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(d, "pmc*.csv"))):
         k = row.get("Kernel_Name", "")[:60]
         acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
     for k, cs in acc.items():
-        if "st_" not in k:
+        if "st_" not in k and "stokes" not in k:
             continue
         print(k, {c: f"{sum(v) / len(v):.4g}" for c, v in cs.items()}, f"n={len(next(iter(cs.values())))}")
 
