@@ -80,7 +80,7 @@ SIGNATURES = {
     "stfem_trace_pop": (None, []),
     "stfem_multi_dot": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _vp]),
     "stfem_multi_axpy": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_vp), _vp, _vp]),
-    "stfem_orthogonalize": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _dp, _vp]),
+    "stfem_orthogonalize": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int64, _dp, _dp, _dp, _vp]),
     "stfem_diagonal_inverse": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp]),
     "stfem_st_diagonal": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _vp, _vp]),
     "stfem_plane_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
@@ -527,13 +527,13 @@ def multi_axpy(ctx, coef, xs, y, stream=None):
 
 
 def orthogonalize(ctx, vs, w, n_own=0, stream=None):
-    """one classical Gram-Schmidt pass on the device: returns (h = V^T w, <w, w> after w -= V h)"""
+    """one classical Gram-Schmidt pass on the device: returns (h = V^T w, <w, w> after w -= V h, <w, w> before)"""
     k = len(vs)
     h = np.zeros(k)
-    n2 = C.c_double(0.0)
+    n2, b2 = C.c_double(0.0), C.c_double(0.0)
     arr = (_vp * k)(*[v._h for v in vs])
-    _check(lib().stfem_orthogonalize(ctx._h, k, arr, w._h, n_own, _p(h), C.byref(n2), stream), "stfem_orthogonalize")
-    return h, n2.value
+    _check(lib().stfem_orthogonalize(ctx._h, k, arr, w._h, n_own, _p(h), C.byref(b2), C.byref(n2), stream), "stfem_orthogonalize")
+    return h, n2.value, b2.value
 
 
 # ------------------------------------------------------------------ space-time multigrid (8 f-2)

@@ -1156,15 +1156,18 @@ int stfem_multi_axpy(stfem_ctx *c, int k, const double *coef, const stfem_vec *c
 
 // One classical Gram-Schmidt pass of w against v_0 .. v_{k-1} entirely on the device: h = V^T w (two-stage reduction),
 // w -= V h with the coefficients read from device memory, h copied to the host at the end (one synchronisation).
-int stfem_orthogonalize(stfem_ctx *c, int k, const stfem_vec *const *vs, stfem_vec *w, int64_t n_own, double *h_out, double *norm2_out,
-                        void *stream)
+int stfem_orthogonalize(stfem_ctx *c, int k, const stfem_vec *const *vs, stfem_vec *w, int64_t n_own, double *h_out, double *norm2_before,
+                        double *norm2_out, void *stream)
 {
-  if (!c || !vs || !w || !h_out || k < 1 || k > 256 - 8 || w->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!c || !vs || !w || !h_out || k < 1 || k > 256 - 9 || w->ctx != c) return STFEM_ERR_INVALID_ARGUMENT;
   if (w->nb > MAX_BLOCKS) return STFEM_ERR_UNSUPPORTED;
   if (n_own <= 0 || n_own > c->ndofs) n_own = c->ndofs;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = multi_dot_device(c, k, vs, w, n_own, c->d_scratch, st);
+  // slots of the scratch array: [0, k) coefficients, k: <w, w> before (rides in the same launch as the coefficients), k + 1: after
+  std::vector<const stfem_vec *> all(vs, vs + k);
+  if (norm2_before) all.push_back(w);
+  int rc = multi_dot_device(c, int(all.size()), all.data(), w, n_own, c->d_scratch, st);
   if (rc != STFEM_OK) return rc == STFEM_ERR_HIP ? hip_fail(hipGetLastError(), "orthogonalize") : rc;
   const unsigned grid = (unsigned)std::min<int64_t>((c->ndofs + 255) / 256, 2048);
   for (int k0 = 0; k0 < k; k0 += DOT_VECS) {
@@ -1183,15 +1186,16 @@ int stfem_orthogonalize(stfem_ctx *c, int k, const stfem_vec *const *vs, stfem_v
   }
   if (norm2_out) { // <w, w> after the projection, in the slot behind the coefficients
     const stfem_vec *ws[1] = {w};
-    rc = multi_dot_device(c, 1, ws, w, n_own, c->d_scratch + k, st);
+    rc = multi_dot_device(c, 1, ws, w, n_own, c->d_scratch + k + 1, st);
     if (rc != STFEM_OK) return rc == STFEM_ERR_HIP ? hip_fail(hipGetLastError(), "orthogonalize") : rc;
   }
   if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "orthogonalize");
-  std::vector<double> host(size_t(k) + 1);
-  HIP_TRY(hipMemcpyAsync(host.data(), c->d_scratch, sizeof(double) * (k + (norm2_out ? 1 : 0)), hipMemcpyDeviceToHost, st));
+  std::vector<double> host(size_t(k) + 2);
+  HIP_TRY(hipMemcpyAsync(host.data(), c->d_scratch, sizeof(double) * (k + 2), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   for (int i = 0; i < k; ++i) h_out[i] = host[i];
-  if (norm2_out) *norm2_out = host[k];
+  if (norm2_before) *norm2_before = host[k];
+  if (norm2_out) *norm2_out = host[k + 1];
   return STFEM_OK;
 }
 

@@ -48,6 +48,7 @@ struct VankaParams {
   int nquad, m, mpad, kpad;
   int colour;         // (cx & 1) + 2 (cy & 1) + 4 (cz & 1) of the cells of this launch
   int p;
+  void *flat;         // two-phase apply (small meshes): Y[slot][mpad], slot = 64 quad + 16 wave + column; nullptr: colour launches
 };
 
 template <typename T> struct Mfma;
@@ -117,28 +118,30 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   const int base = prm.cell[(quad * 4 + wave) * 16 + (lane & 15)]; // this lane's cell (column of X and Y)
   const char *src0 = static_cast<const char *>(prm.src[0]) + (long long)(base < 0 ? 0 : base) * (long long)sizeof(T);
   char *dst0 = static_cast<char *>(prm.dst[0]) + (long long)(base < 0 ? 0 : base) * (long long)sizeof(T);
-  // rows [s KS, (s + 1) KS) of the (padded) inverse: fetched into registers while the previous slab is
-  // multiplied, written to the other LDS buffer afterwards.  (global_load_lds_dwordx4 straight into LDS - no
-  // registers, no ds_write - measured 3-10 % SLOWER here: profiles/r2/vanka.)
+  // rows [s KS, (s + 1) KS) of the (padded) inverse: fetched into registers DEPTH slabs ahead of their use, written to the
+  // other LDS buffer after the slab before has been multiplied.  (One slab ahead, as in round 2, leaves a full global-load
+  // latency in every step of the k loop: on the small multigrid levels, where a launch is a handful of workgroups, a step took
+  // 1.7 us.  global_load_lds_dwordx4 straight into LDS - no registers, no ds_write - measured 3-10 % SLOWER: profiles/r2/vanka.)
+  constexpr int DEPTH = 3;
   constexpr int SR = (KS * MPAD + 255) / 256; // slab elements every thread moves
-  T sreg[SR];
-  auto fetch = [&](int s) {
+  T sreg[DEPTH][SR];
+  auto fetch = [&](int s, T (&reg)[SR]) {
     const T *g = Binv + size_t(s) * KS * prm.mpad;
 #pragma unroll
     for (int q = 0; q < SR; ++q) {
       const int e = q * 256 + int(threadIdx.x); // element (k row e / MPAD, column e % MPAD) of the slab
-      if (KS * MPAD % 256 == 0 || e < KS * MPAD) sreg[q] = g[(e / MPAD) * prm.mpad + e % MPAD];
+      if (KS * MPAD % 256 == 0 || e < KS * MPAD) reg[q] = g[(e / MPAD) * prm.mpad + e % MPAD];
     }
   };
-  auto deposit = [&](int buf) {
+  auto deposit = [&](int buf, const T (&reg)[SR]) {
 #pragma unroll
     for (int q = 0; q < SR; ++q)
-      if (KS * MPAD % 256 == 0 || q * 256 + int(threadIdx.x) < KS * MPAD) slab[buf][q * 256 + threadIdx.x] = sreg[q];
+      if (KS * MPAD % 256 == 0 || q * 256 + int(threadIdx.x) < KS * MPAD) slab[buf][q * 256 + threadIdx.x] = reg[q];
   };
   typename M::acc_t acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = typename M::acc_t{0, 0, 0, 0};
-  // this lane's row of X in a k-step: krow = 4 step + (lane >> 4); the values are gathered one slab ahead
+  // this lane's row of X in a k-step: krow = 4 step + (lane >> 4); the values are gathered DEPTH slabs ahead, in slab order
   int krow = lane >> 4;
   auto gather = [&]() -> T {
     T v = T(0);
@@ -150,32 +153,54 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
     return v;
   };
   const int nslab = prm.kpad / KS;
-  fetch(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < nslab) fetch(d, sreg[d]);
   __syncthreads(); // the offset tables
-  T xcur[KS / 4], xnxt[KS / 4];
+  T xr[DEPTH][KS / 4];
 #pragma unroll
-  for (int q = 0; q < KS / 4; ++q) xcur[q] = gather();
-  deposit(0);
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < nslab) {
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) xr[d][q] = gather();
+    }
+  deposit(0, sreg[0]);
   __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) {
-      fetch(s + 1);
+  for (int s0 = 0; s0 < nslab; s0 += DEPTH) {
 #pragma unroll
-      for (int q = 0; q < KS / 4; ++q) xnxt[q] = gather();
+    for (int d = 0; d < DEPTH; ++d) { // slab s lives in register slot s % DEPTH = d
+      const int s = s0 + d;
+      if (s < nslab) {                // (uniform)
+        const bool more = s + DEPTH < nslab;
+        T xnew[KS / 4];
+        if (more) {
+          fetch(s + DEPTH, sreg[d]);  // slot d went to LDS in the step before
+#pragma unroll
+          for (int q = 0; q < KS / 4; ++q) xnew[q] = gather();
+        }
+        const T *sl = slab[s & 1];
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          const T *a = sl + (4 * q + (lane >> 4)) * MPAD + (lane & 15);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t] = M::mma(a[16 * t], xr[d][q], acc[t]);
+        }
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < KS / 4; ++q) xr[d][q] = xnew[q];
+        }
+        if (s + 1 < nslab) deposit((s + 1) & 1, sreg[(d + 1) % DEPTH]);
+        __syncthreads();
+      }
     }
-    const T *sl = slab[s & 1];
+  }
+  if (prm.flat) { // two-phase apply: the cell's rows go to the scratch array, vanka_collect_kernel sums them per DoF
+    T *y = static_cast<T *>(prm.flat) + (size_t(quad) * 64 + wave * 16 + (lane & 15)) * prm.mpad + row0;
 #pragma unroll
-    for (int q = 0; q < KS / 4; ++q) {
-      const T *a = sl + (4 * q + (lane >> 4)) * MPAD + (lane & 15);
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = M::mma(a[16 * t], xcur[q], acc[t]);
-    }
-    if (s + 1 < nslab) {
-      deposit((s + 1) & 1);
-#pragma unroll
-      for (int q = 0; q < KS / 4; ++q) xcur[q] = xnxt[q];
-    }
-    __syncthreads();
+      for (int r = 0; r < 4; ++r) y[16 * t + M::row(lane, r)] = acc[t][r];
+    return;
   }
   // scatter: rows of Y back to the DoFs of the cell (cells of one launch share none).  All loads first
   // (first touches, rows beyond the block and padding cells load nothing), then the stores.
@@ -246,6 +271,7 @@ struct VankaCellParams {
   const int *cell;    // [ncell of this colour]: cell number
   int m, mpad, kpad, nloc, p, colour;
   int ncx, ncy, ncz, nx, ny;
+  void *flat;         // two-phase apply (small meshes): Y[cell][mpad]; nullptr: colour launches
 };
 
 // y = B_c^-1 x per cell, the block streamed from HBM once (the reference's apply: stmg.h:845-867): one workgroup per
@@ -254,7 +280,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void vanka_apply_percell_kernel(const VankaCellParams prm)
 {
   __shared__ T xs[VK_MAX_ROWS];
-  const int cell = prm.cell[blockIdx.x];
+  const int cell = prm.flat ? int(blockIdx.x) : prm.cell[blockIdx.x];
   const int cx = cell % prm.ncx, cy = (cell / prm.ncx) % prm.ncy, cz = cell / (prm.ncx * prm.ncy);
   const long long base = (long long)prm.p * cx + (long long)prm.nx * ((long long)prm.p * cy + (long long)prm.ny * prm.p * cz);
   for (int r = threadIdx.x; r < prm.kpad; r += 256) {
@@ -283,6 +309,10 @@ __global__ __launch_bounds__(256) void vanka_apply_percell_kernel(const VankaCel
     }
     for (; k < prm.kpad; ++k) a0 = fma(col[(size_t)k * prm.mpad], xs[k], a0);
     const T y = (a0 + a1) + (a2 + a3);
+    if (prm.flat) {
+      static_cast<T *>(prm.flat)[size_t(cell) * prm.mpad + r] = y;
+      continue;
+    }
     const int blk = r / prm.nloc, n = r - blk * prm.nloc;
     T *dp = static_cast<T *>(prm.dst[0]);
 #pragma unroll
@@ -303,6 +333,55 @@ __global__ __launch_bounds__(256) void vanka_apply_percell_kernel(const VankaCel
   }
 }
 
+
+// Second phase of the two-phase apply (small meshes, where eight colour launches of ~20 us each are all latency): every DoF sums
+// the rows its (up to eight) cells left in the scratch array, in a fixed order (z, y, x of the cells) - reproducible - and
+// stores: dst = sum over cells of scatter(B_c^-1 gather(src)) (stmg.h:836-867) in two launches instead of eight.
+struct VankaCollectParams {
+  void *dst[VK_MAX_BLOCKS];
+  const void *y;    // [slot][mpad]
+  const int *slot;  // cell -> slot (nullptr: slot = cell)
+  int nb, nloc, p, mpad;
+  int ncx, ncy, ncz, nx, ny, nz;
+};
+template <typename T> __global__ __launch_bounds__(256) void vanka_collect_kernel(const VankaCollectParams prm)
+{
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)prm.nx * prm.ny * prm.nz) return;
+  const int ix = int(i % prm.nx), iy = int((i / prm.nx) % prm.ny), iz = int(i / ((long long)prm.nx * prm.ny));
+  const int p = prm.p, np = p + 1;
+  // per direction: the cells holding node i and its local index there (a vertex node: the cell below with index p, then the cell above with 0)
+  int cc[3][2], ll[3][2], cnt[3];
+  const int idx[3] = {ix, iy, iz}, nc[3] = {prm.ncx, prm.ncy, prm.ncz};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int c0 = idx[d] / p, l0 = idx[d] - c0 * p;
+    cnt[d] = 0;
+    if (l0 == 0) {
+      if (c0 > 0) { cc[d][cnt[d]] = c0 - 1; ll[d][cnt[d]] = p; ++cnt[d]; }
+      if (c0 < nc[d]) { cc[d][cnt[d]] = c0; ll[d][cnt[d]] = 0; ++cnt[d]; }
+    } else {
+      cc[d][0] = c0; ll[d][0] = l0; cnt[d] = 1;
+    }
+  }
+  T acc[VK_MAX_BLOCKS];
+#pragma unroll
+  for (int b = 0; b < VK_MAX_BLOCKS; ++b) acc[b] = T(0);
+  const T *Y = static_cast<const T *>(prm.y);
+  for (int kz = 0; kz < cnt[2]; ++kz)
+    for (int ky = 0; ky < cnt[1]; ++ky)
+      for (int kx = 0; kx < cnt[0]; ++kx) {
+        const int cell = cc[0][kx] + prm.ncx * (cc[1][ky] + prm.ncy * cc[2][kz]);
+        const int n = ll[0][kx] + np * (ll[1][ky] + np * ll[2][kz]);
+        const T *row = Y + size_t(prm.slot ? prm.slot[cell] : cell) * prm.mpad + n;
+#pragma unroll
+        for (int b = 0; b < VK_MAX_BLOCKS; ++b)
+          if (b < prm.nb) acc[b] += row[b * prm.nloc];
+      }
+#pragma unroll
+  for (int b = 0; b < VK_MAX_BLOCKS; ++b)
+    if (b < prm.nb) static_cast<T *>(prm.dst[b])[i] = acc[b];
+}
 
 // ---- device-side set-up of the per-cell blocks (large general meshes: MI355X holds the reference's one-block-per-cell layout of
 // a whole configs[2] / configs[3] mesh in HBM; the set-up must then not go through the host either) ----
@@ -490,7 +569,19 @@ struct stfem_vanka {
   int nquad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool per_cell = false; // one block per cell (general meshes, coefficient tables): d_blocks is [cell][kpad][mpad]
   int ncol[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // cells per colour (d_cell[colour] = their numbers)
+  // two-phase apply (meshes of up to VK_FLAT_CELLS cells): all cells in ONE launch, rows to d_flat, then vanka_collect_kernel
+  bool flat = false;
+  void *d_flat = nullptr;
+  int *d_cell_all = nullptr, *d_cls_all = nullptr, *d_slot = nullptr;
+  int nquad_all = 0;
 };
+constexpr long long VK_FLAT_CELLS = 50000; // (36^3 cells: 45 us instead of 8 x 23; at 72^3 the scratch traffic costs more than the launches)
+static bool vanka_wants_flat(const stfem_ctx *c)
+{
+  if (const char *e = getenv("STFEM_VANKA_COLOURS")) // (tests and measurements: the colour launches on small meshes too)
+    if (atoi(e)) return false;
+  return c->ncells <= VK_FLAT_CELLS;
+}
 
 #define VK_TRY(call)                                                                  \
   do {                                                                                \
@@ -528,6 +619,27 @@ static int vanka_launch(const stfem_vanka *v, VankaParams &prm, int nquad, hipSt
   if (!k) return STFEM_ERR_UNSUPPORTED;
   void *args[] = {&prm};
   return hipLaunchKernel(k, dim3(nquad, v->parts), dim3(256), args, 0, st) == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+
+static int vanka_collect(const stfem_vanka *v, stfem_vec *dst, hipStream_t st)
+{
+  const stfem_ctx *c = v->ctx;
+  VankaCollectParams cp;
+  std::memset(&cp, 0, sizeof(cp));
+  for (int i = 0; i < v->nb; ++i) cp.dst[i] = dst->blk[i];
+  cp.y = v->d_flat;
+  cp.slot = v->d_slot;
+  cp.nb = v->nb; cp.nloc = v->nloc; cp.p = c->p; cp.mpad = v->mpad;
+  cp.ncx = c->nc[0]; cp.ncy = c->nc[1]; cp.ncz = c->nc[2]; cp.nx = c->nd[0]; cp.ny = c->nd[1]; cp.nz = c->nd[2];
+  const unsigned grid = (unsigned)((c->ndofs + 255) / 256);
+  if (c->prec) hipLaunchKernelGGL(vanka_collect_kernel<float>, dim3(grid), dim3(256), 0, st, cp);
+  else hipLaunchKernelGGL(vanka_collect_kernel<double>, dim3(grid), dim3(256), 0, st, cp);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_vanka_err, sizeof(g_vanka_err), "vanka_collect_kernel: %s", hipGetErrorString(e));
+    return STFEM_ERR_HIP;
+  }
+  return STFEM_OK;
 }
 
 // Row tiles (16 rows each) per workgroup: a cell block of `tiles` tiles is split into parts of mtw tiles, one
@@ -579,6 +691,15 @@ static int vanka_per_cell_tables(stfem_vanka *v)
         hipMemcpy(v->d_cell[colour], cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
       return STFEM_ERR_HIP;
   }
+  return STFEM_OK;
+}
+
+// two-phase apply of the per-cell variant: the scratch array (slot = cell)
+static int vanka_flat_per_cell(stfem_vanka *v)
+{
+  if (!vanka_wants_flat(v->ctx)) return STFEM_OK;
+  if (hipMalloc(&v->d_flat, size_t(v->ctx->ncells) * v->mpad * v->ctx->es) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
+  v->flat = true;
   return STFEM_OK;
 }
 
@@ -847,7 +968,8 @@ int stfem_vanka_create_partitioned(stfem_ctx *c, int nb, const double *Alpha, co
       delete v;
       return STFEM_ERR_UNSUPPORTED;
     }
-    const int rc = vanka_create_per_cell(v, Alpha, Beta);
+    int rc = vanka_create_per_cell(v, Alpha, Beta);
+    if (rc == STFEM_OK) rc = vanka_flat_per_cell(v);
     if (rc != STFEM_OK) {
       stfem_vanka_destroy(v);
       return rc;
@@ -1005,6 +1127,34 @@ int stfem_vanka_create_partitioned(stfem_ctx *c, int nb, const double *Alpha, co
       return STFEM_ERR_HIP;
     }
   }
+  if (vanka_wants_flat(c)) { // two-phase apply: all cells in one launch, grouped by class; cell -> slot for the second phase
+    std::map<int, std::vector<std::pair<int, int>>> by_class; // class -> (first DoF, cell number)
+    for (int cz = 0; cz < c->nc[2]; ++cz)
+      for (int cy = 0; cy < c->nc[1]; ++cy)
+        for (int cx = 0; cx < c->nc[0]; ++cx) {
+          const int key = dir_class(0, cx) | (dir_class(1, cy) << 2) | (dir_class(2, cz) << 4);
+          by_class[class_id[key]].push_back({p * cx + c->nd[0] * (p * cy + c->nd[1] * p * cz), cx + c->nc[0] * (cy + c->nc[1] * cz)});
+        }
+    std::vector<int> cells, cls, slot(size_t(c->ncells), 0);
+    for (auto &kv : by_class) {
+      for (const auto &e : kv.second) {
+        slot[e.second] = int(cells.size());
+        cells.push_back(e.first);
+      }
+      cells.resize(((cells.size() + 63) / 64) * 64, -1);
+      while (cls.size() < cells.size() / 64) cls.push_back(kv.first);
+    }
+    v->nquad_all = int(cls.size());
+    if (hipMalloc(&v->d_cell_all, cells.size() * sizeof(int)) != hipSuccess || hipMalloc(&v->d_cls_all, cls.size() * sizeof(int)) != hipSuccess ||
+        hipMalloc(&v->d_slot, slot.size() * sizeof(int)) != hipSuccess || hipMalloc(&v->d_flat, cells.size() * v->mpad * c->es) != hipSuccess ||
+        hipMemcpy(v->d_cell_all, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_cls_all, cls.data(), cls.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(v->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      stfem_vanka_destroy(v);
+      return STFEM_ERR_HIP;
+    }
+    v->flat = true;
+  }
   *out = v;
   return STFEM_OK;
 }
@@ -1054,6 +1204,7 @@ int stfem_vanka_create_partitioned_general(stfem_ctx *slab, stfem_ctx *extended,
   stfem_vanka_destroy(ve);
   VK_TRY(hipSetDevice(slab->device));
   rc = vanka_per_cell_tables(v);
+  if (rc == STFEM_OK) rc = vanka_flat_per_cell(v);
   if (rc != STFEM_OK) {
     stfem_vanka_destroy(v);
     return rc;
@@ -1069,6 +1220,10 @@ void stfem_vanka_destroy(stfem_vanka *v)
   if (v->d_blocks_base) (void)hipFree(v->d_blocks_base);
   else if (v->d_blocks) (void)hipFree(v->d_blocks);
   if (v->d_off) (void)hipFree(v->d_off);
+  if (v->d_flat) (void)hipFree(v->d_flat);
+  if (v->d_cell_all) (void)hipFree(v->d_cell_all);
+  if (v->d_cls_all) (void)hipFree(v->d_cls_all);
+  if (v->d_slot) (void)hipFree(v->d_slot);
   for (int i = 0; i < 8; ++i) {
     if (v->d_cell[i]) (void)hipFree(v->d_cell[i]);
     if (v->d_cls[i]) (void)hipFree(v->d_cls[i]);
@@ -1111,6 +1266,12 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
     cp.m = v->m; cp.mpad = v->mpad; cp.kpad = v->kpad; cp.nloc = v->nloc; cp.p = c->p;
     cp.ncx = c->nc[0]; cp.ncy = c->nc[1]; cp.ncz = c->nc[2]; cp.nx = c->nd[0]; cp.ny = c->nd[1];
     (void)hipGetLastError();
+    if (v->flat) {
+      cp.flat = v->d_flat;
+      if (c->prec) hipLaunchKernelGGL(vanka_apply_percell_kernel<float>, dim3((unsigned)c->ncells), dim3(256), 0, st, cp);
+      else hipLaunchKernelGGL(vanka_apply_percell_kernel<double>, dim3((unsigned)c->ncells), dim3(256), 0, st, cp);
+      return vanka_collect(v, dst, st);
+    }
     for (int colour = 0; colour < 8; ++colour) {
       if (v->ncol[colour] == 0) continue;
       cp.cell = v->d_cell[colour];
@@ -1136,6 +1297,18 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
   prm.m = v->m; prm.mpad = v->mpad; prm.kpad = v->kpad;
   prm.p = c->p;
   (void)hipGetLastError();
+  if (v->flat) {
+    prm.cell = v->d_cell_all;
+    prm.cls = v->d_cls_all;
+    prm.nquad = v->nquad_all;
+    prm.flat = v->d_flat;
+    const int rc = vanka_launch(v, prm, prm.nquad, st);
+    if (rc != STFEM_OK) {
+      snprintf(g_vanka_err, sizeof(g_vanka_err), "vanka_apply_kernel: %s", hipGetErrorString(hipGetLastError()));
+      return rc;
+    }
+    return vanka_collect(v, dst, st);
+  }
   for (int colour = 0; colour < 8; ++colour) {
     if (v->nquad[colour] == 0) continue;
     prm.cell = v->d_cell[colour];

@@ -28,10 +28,11 @@ template <typename Number> void set_zero(BlockVectorT<Number> &v, void *stream =
 template <typename Number> double norm(const BlockVectorT<Number> &x) { return std::sqrt(dot(x, x)); }
 
 // The Gram-Schmidt step of the Krylov solvers: w is orthogonalised against v_0 .. v_{k-1}, h[i] receives the
-// coefficients, the return value is ||w|| afterwards.  One rank: the re-orthogonalised classical scheme on the device
-// (stfem_orthogonalize twice: a handful of launches and two read-backs whatever k is; deal.II's SolverGMRES uses a
-// classical scheme with delayed re-orthogonalisation for the same reason).  Partitioned vectors: the modified scheme
-// with one reducing inner product per vector (stfem_dot_global), as before.
+// coefficients, the return value is ||w|| afterwards.  One rank: the classical scheme on the device with a second pass
+// only when the first one cancelled most of w (||w|| fell below a tenth: the loss of orthogonality of one classical pass
+// is eps ||w||_before / ||w||_after; deal.II's SolverGMRES re-orthogonalises on such a test too) - a handful of launches
+// and one or two read-backs whatever k is.  Partitioned vectors: the modified scheme with one reducing inner product per
+// vector (stfem_dot_global), as before.
 template <typename Number> double orthogonalize(const std::vector<BlockVectorT<Number>> &vs, unsigned k, BlockVectorT<Number> &w, double *h)
 {
   const Context &c = *w.context();
@@ -44,11 +45,13 @@ template <typename Number> double orthogonalize(const std::vector<BlockVectorT<N
   }
   std::vector<const stfem_vec *> handles(k);
   for (unsigned i = 0; i < k; ++i) handles[i] = vs[i].handle();
-  std::vector<double> h2(k);
-  double n2 = 0.0;
-  check(stfem_orthogonalize(c.h, int(k), handles.data(), w.handle(), 0, h, nullptr, nullptr), "stfem_orthogonalize");
-  check(stfem_orthogonalize(c.h, int(k), handles.data(), w.handle(), 0, h2.data(), &n2, nullptr), "stfem_orthogonalize");
-  for (unsigned i = 0; i < k; ++i) h[i] += h2[i];
+  double before = 0.0, n2 = 0.0;
+  check(stfem_orthogonalize(c.h, int(k), handles.data(), w.handle(), 0, h, &before, &n2, nullptr), "stfem_orthogonalize");
+  if (!(n2 > 0.01 * before)) {
+    std::vector<double> h2(k);
+    check(stfem_orthogonalize(c.h, int(k), handles.data(), w.handle(), 0, h2.data(), nullptr, &n2, nullptr), "stfem_orthogonalize");
+    for (unsigned i = 0; i < k; ++i) h[i] += h2[i];
+  }
   return std::sqrt(std::max(n2, 0.0));
 }
 

@@ -156,12 +156,14 @@ int stfem_dot(stfem_ctx *ctx, const stfem_vec *a, const stfem_vec *b, int64_t n_
  *   multi_dot:     out[i] = <a_i, b>, i < k (host array; synchronous)
  *   multi_axpy:    y += sum_i coef_i x_i (coefficients from the host; asynchronous)
  *   orthogonalize: one classical Gram-Schmidt pass h = V^T w, w -= V h with the coefficients kept on the device, then
- *                  h_out[0 .. k) <- h and, if norm2_out is given, <w, w> after the projection (synchronous).  Twice in a row it
- *                  is the re-orthogonalised classical scheme (as stable as the modified one, k times fewer launches and waits). */
+ *                  h_out[0 .. k) <- h; if given, norm2_before <- <w, w> before the projection (rides in the launch of the
+ *                  coefficients) and norm2_out <- <w, w> after it (synchronous).  Twice in a row it is the re-orthogonalised
+ *                  classical scheme (as stable as the modified one, k times fewer launches and waits); the second pass is only
+ *                  needed when the projection cancelled most of w (norm2_out << norm2_before), which the two norms tell. */
 int stfem_multi_dot(stfem_ctx *ctx, int k, const stfem_vec *const *a, const stfem_vec *b, int64_t n_own, double *out, void *stream);
 int stfem_multi_axpy(stfem_ctx *ctx, int k, const double *coef, const stfem_vec *const *x, stfem_vec *y, void *stream);
-int stfem_orthogonalize(stfem_ctx *ctx, int k, const stfem_vec *const *v, stfem_vec *w, int64_t n_own, double *h_out, double *norm2_out,
-                        void *stream);
+int stfem_orthogonalize(stfem_ctx *ctx, int k, const stfem_vec *const *v, stfem_vec *w, int64_t n_own, double *h_out, double *norm2_before,
+                        double *norm2_out, void *stream);
 
 /* Halo support for z-slab partitions (deal.II: update_ghost_values / compress(add) inside
  * MatrixFree::cell_loop, operators.h:1016-1017).  A rank's top DoF plane (iz = nz-1) is the

@@ -322,7 +322,8 @@ def test_gram_schmidt_step_on_the_device(number, stfem):
     stfem.multi_axpy(ctx, coef, vs, w)
     W2 = w.download()
     assert rel(W2, W + sum(c * v for c, v in zip(coef, V))) < (1e-14 if number == "double" else 1e-6)
-    h, n2 = stfem.orthogonalize(ctx, vs, w)
+    h, n2, b2 = stfem.orthogonalize(ctx, vs, w)
+    assert abs(b2 - np.sum(W2 ** 2)) <= (1e-12 if number == "double" else 1e-5) * b2
     hw = np.array([np.sum(v * W2) for v in V])
     assert np.allclose(h, hw, rtol=tol, atol=tol * np.abs(hw).max())
     W3 = W2 - sum(c * v for c, v in zip(h, V))

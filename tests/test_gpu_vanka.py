@@ -13,6 +13,20 @@ def rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
 
 
+# the apply has two schemes: eight colour launches with the scatter fused in (large meshes) and, on meshes of up to 50 000 cells,
+# all cells in one launch + one collecting launch (csrc/stfem_vanka.hip); STFEM_VANKA_COLOURS=1 (read when the smoother is
+# created) forces the first on small meshes too
+SCHEMES = ["two-phase", "colours"]
+
+
+def _scheme(monkeypatch, scheme):
+    if scheme == "colours":
+        monkeypatch.setenv("STFEM_VANKA_COLOURS", "1")
+    else:
+        monkeypatch.delenv("STFEM_VANKA_COLOURS", raising=False)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("number", ["double", "float"])
 @pytest.mark.parametrize("p,nc,ttype,r,mask,upper,nsteps", [
     (2, (3, 3, 3), 0, 2, 63, (1.0, 1.0, 1.0), 1),
@@ -23,9 +37,10 @@ def rel(a, b):
     (2, (1, 1, 1), 0, 2, 63, (1.0, 1.0, 1.0), 1),   # a single cell: the exact inverse
     (2, (2, 1, 4), 0, 3, 63 & ~3, (1.0, 1.0, 1.0), 1),  # three temporal blocks, 81 rows -> padded tiles
 ])
-def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, nsteps, number):
+def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, nsteps, number, scheme, monkeypatch):
     from oracle import vanka_oracle
     stfem = importlib.import_module("dealii-stfem_amd")
+    _scheme(monkeypatch, scheme)
     Alpha, Beta, _, _ = stfem.get_fe_time_weights(ttype, r, 0.05, nsteps)
     nb = Alpha.shape[0]
     ctx = stfem.MatrixFreeOperator(p, nc, lower=(0, 0, 0), upper=upper, number=number, dirichlet_mask=mask)
@@ -51,6 +66,7 @@ def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, nsteps, number):
         V.vmult(src, src)
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("number", ["double", "float"])
 @pytest.mark.parametrize("p,nc,ttype,r,mask,distort,coef", [
     (2, (3, 3, 2), 0, 2, 63, 0.12, None),        # perturbed mesh
@@ -58,11 +74,12 @@ def test_vanka_vs_oracle(p, nc, ttype, r, mask, upper, nsteps, number):
     (3, (3, 2, 3), 1, 1, 63 & ~12, 0.0, "cell"),  # Cartesian mesh, discontinuous laplace coefficient (cfg 3's setting)
     (2, (2, 3, 2), 0, 1, 63, 0.1, "q"),          # per-quadrature-point coefficient on a perturbed mesh
 ])
-def test_vanka_per_cell_blocks_vs_oracle(p, nc, ttype, r, mask, distort, coef, number):
+def test_vanka_per_cell_blocks_vs_oracle(p, nc, ttype, r, mask, distort, coef, number, scheme, monkeypatch):
     """General meshes and coefficient tables: one block per cell (set-up from device-computed cell matrices,
     HBM-streaming apply), against the same dense restatement."""
     from oracle import vanka_oracle
     stfem = importlib.import_module("dealii-stfem_amd")
+    _scheme(monkeypatch, scheme)
     Alpha, Beta, _, _ = stfem.get_fe_time_weights(ttype, r, 0.05, 1)
     nb = Alpha.shape[0]
     verts = stfem.mesh_vertices(nc, distort=distort, seed=11)
@@ -95,11 +112,13 @@ def test_vanka_per_cell_blocks_vs_oracle(p, nc, ttype, r, mask, distort, coef, n
     assert np.array_equal(dst.download(), Y)
 
 
-def test_vanka_blocks_at_descending_addresses():
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_vanka_blocks_at_descending_addresses(scheme, monkeypatch):
     """The block arrays of a vector may lie anywhere: the kernel's offset tables hold differences to block 0 that are
     negative when a later block sits at a lower address (found by the slab driver: FGMRES stagnated on 12^3 cells)."""
     from oracle import vanka_oracle
     stfem = importlib.import_module("dealii-stfem_amd")
+    _scheme(monkeypatch, scheme)
     p, nc = 2, (3, 2, 3)
     Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
     nb = Alpha.shape[0]
