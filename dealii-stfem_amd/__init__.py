@@ -138,6 +138,7 @@ SIGNATURES = {
     "stfem_vanka_n_classes": (C.c_int, [_vp]),
     "stfem_vanka_plan": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "stfem_vanka_vmult": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "stfem_vanka_step": (C.c_int, [_vp, _vp, C.c_double, C.c_int, _vp, _vp]),
     "stfem_vanka_last_error": (C.c_char_p, []),
     "stfem_fe_time_weights": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
     "stfem_fe_time_weights_wave": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int,
@@ -441,6 +442,10 @@ class PreconditionVanka:
         _check(lib().stfem_vanka_vmult(self._h, dst._h, src._h, stream), "stfem_vanka_vmult")
 
     smooth = vmult  # stmg.h:881-885
+
+    def step(self, dst, omega, accumulate, src, stream=None):
+        """dst = (dst if accumulate else 0) + omega * vmult(src): the relaxation step around the smoother (stmg.h:1199-1238)"""
+        _check(lib().stfem_vanka_step(self._h, dst._h, omega, int(bool(accumulate)), src._h, stream), "stfem_vanka_step")
 
 
 class SystemMatrix:

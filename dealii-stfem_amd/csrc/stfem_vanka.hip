@@ -49,6 +49,8 @@ struct VankaParams {
   int colour;         // (cx & 1) + 2 (cy & 1) + 4 (cz & 1) of the cells of this launch
   int p;
   void *flat;         // two-phase apply (small meshes): Y[slot][mpad], slot = 64 quad + 16 wave + column; nullptr: colour launches
+  double omega;       // dst = (accumulate ? dst : 0) + omega * (sum over cells ...)  (the relaxation step around the smoother)
+  int accumulate;
 };
 
 template <typename T> struct Mfma;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
         const bool shared = (idx[dd] == 0 && (k & 1)) || (idx[dd] == prm.p && (k & 2));
         if (shared && ((prm.colour >> dd) & 1)) first = false;
       }
-      if (first) od |= 1;
+      if (first && !prm.accumulate) od |= 1;
     }
     s_src[r] = os;
     if (r >= row0 && r < row0 + MPAD) s_dst[r - row0] = od;
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
   // (first touches, rows beyond the block and padding cells load nothing), then the stores.
   // (two row tiles = eight loads in flight per lane at a time: more only costs registers)
   constexpr int TC = MT >= 2 ? 2 : 1;
+  const T om = T(prm.omega);
 #pragma unroll
   for (int t0 = 0; t0 < MT; t0 += TC) {
     T *d[TC * 4];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void vanka_apply_kernel(const VankaParams p
     for (int t = 0; t < TC; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (t0 + t < MT && d[4 * t + r]) *d[4 * t + r] = old[4 * t + r] + acc[t0 + t][r];
+        if (t0 + t < MT && d[4 * t + r]) *d[4 * t + r] = old[4 * t + r] + om * acc[t0 + t][r];
   }
 }
 
@@ -272,6 +275,8 @@ struct VankaCellParams {
   int m, mpad, kpad, nloc, p, colour;
   int ncx, ncy, ncz, nx, ny;
   void *flat;         // two-phase apply (small meshes): Y[cell][mpad]; nullptr: colour launches
+  double omega;
+  int accumulate;
 };
 
 // y = B_c^-1 x per cell, the block streamed from HBM once (the reference's apply: stmg.h:845-867): one workgroup per
@@ -329,7 +334,8 @@ __global__ __launch_bounds__(256) void vanka_apply_percell_kernel(const VankaCel
       if (shared && ((prm.colour >> d) & 1)) first = false;
     }
     T *q = dp + base + prm.off[n];
-    *q = first ? y : *q + y;
+    const T oy = T(prm.omega) * y;
+    *q = (first && !prm.accumulate) ? oy : *q + oy;
   }
 }
 
@@ -343,6 +349,8 @@ struct VankaCollectParams {
   const int *slot;  // cell -> slot (nullptr: slot = cell)
   int nb, nloc, p, mpad;
   int ncx, ncy, ncz, nx, ny, nz;
+  double omega;
+  int accumulate;
 };
 template <typename T> __global__ __launch_bounds__(256) void vanka_collect_kernel(const VankaCollectParams prm)
 {
@@ -380,7 +388,10 @@ template <typename T> __global__ __launch_bounds__(256) void vanka_collect_kerne
       }
 #pragma unroll
   for (int b = 0; b < VK_MAX_BLOCKS; ++b)
-    if (b < prm.nb) static_cast<T *>(prm.dst[b])[i] = acc[b];
+    if (b < prm.nb) {
+      T *d = static_cast<T *>(prm.dst[b]) + i;
+      *d = prm.accumulate ? *d + T(prm.omega) * acc[b] : T(prm.omega) * acc[b];
+    }
 }
 
 // ---- device-side set-up of the per-cell blocks (large general meshes: MI355X holds the reference's one-block-per-cell layout of
@@ -621,7 +632,7 @@ static int vanka_launch(const stfem_vanka *v, VankaParams &prm, int nquad, hipSt
   return hipLaunchKernel(k, dim3(nquad, v->parts), dim3(256), args, 0, st) == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
 }
 
-static int vanka_collect(const stfem_vanka *v, stfem_vec *dst, hipStream_t st)
+static int vanka_collect(const stfem_vanka *v, stfem_vec *dst, double omega, int accumulate, hipStream_t st)
 {
   const stfem_ctx *c = v->ctx;
   VankaCollectParams cp;
@@ -631,6 +642,7 @@ static int vanka_collect(const stfem_vanka *v, stfem_vec *dst, hipStream_t st)
   cp.slot = v->d_slot;
   cp.nb = v->nb; cp.nloc = v->nloc; cp.p = c->p; cp.mpad = v->mpad;
   cp.ncx = c->nc[0]; cp.ncy = c->nc[1]; cp.ncz = c->nc[2]; cp.nx = c->nd[0]; cp.ny = c->nd[1]; cp.nz = c->nd[2];
+  cp.omega = omega; cp.accumulate = accumulate;
   const unsigned grid = (unsigned)((c->ndofs + 255) / 256);
   if (c->prec) hipLaunchKernelGGL(vanka_collect_kernel<float>, dim3(grid), dim3(256), 0, st, cp);
   else hipLaunchKernelGGL(vanka_collect_kernel<double>, dim3(grid), dim3(256), 0, st, cp);
@@ -1239,7 +1251,11 @@ int stfem_vanka_plan(const stfem_vanka *v, int32_t out[2])
   return STFEM_OK;
 }
 
-int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream)
+int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream) { return stfem_vanka_step(v, dst, 1.0, 0, src, stream); }
+
+// dst = (accumulate ? dst : 0) + omega * V src: the relaxation step x <- x + omega P^-1 r of the multigrid smoothers
+// (PreconditionRelaxation around the Vanka smoother, stmg.h:1199-1238) without a temporary vector and a separate update pass
+int stfem_vanka_step(stfem_vanka *v, stfem_vec *dst, double omega, int accumulate, const stfem_vec *src, void *stream)
 {
   if (!v || !dst || !src) return STFEM_ERR_INVALID_ARGUMENT;
   struct Scope { // the reference's TimerOutput scope "vanka" (stmg.h:835)
@@ -1265,12 +1281,13 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
     cp.off = v->d_off;
     cp.m = v->m; cp.mpad = v->mpad; cp.kpad = v->kpad; cp.nloc = v->nloc; cp.p = c->p;
     cp.ncx = c->nc[0]; cp.ncy = c->nc[1]; cp.ncz = c->nc[2]; cp.nx = c->nd[0]; cp.ny = c->nd[1];
+    cp.omega = omega; cp.accumulate = accumulate;
     (void)hipGetLastError();
     if (v->flat) {
       cp.flat = v->d_flat;
       if (c->prec) hipLaunchKernelGGL(vanka_apply_percell_kernel<float>, dim3((unsigned)c->ncells), dim3(256), 0, st, cp);
       else hipLaunchKernelGGL(vanka_apply_percell_kernel<double>, dim3((unsigned)c->ncells), dim3(256), 0, st, cp);
-      return vanka_collect(v, dst, st);
+      return vanka_collect(v, dst, omega, accumulate, st);
     }
     for (int colour = 0; colour < 8; ++colour) {
       if (v->ncol[colour] == 0) continue;
@@ -1296,6 +1313,7 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
   prm.off = v->d_off;
   prm.m = v->m; prm.mpad = v->mpad; prm.kpad = v->kpad;
   prm.p = c->p;
+  prm.omega = omega; prm.accumulate = accumulate;
   (void)hipGetLastError();
   if (v->flat) {
     prm.cell = v->d_cell_all;
@@ -1307,7 +1325,7 @@ int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void
       snprintf(g_vanka_err, sizeof(g_vanka_err), "vanka_apply_kernel: %s", hipGetErrorString(hipGetLastError()));
       return rc;
     }
-    return vanka_collect(v, dst, st);
+    return vanka_collect(v, dst, omega, accumulate, st);
   }
   for (int colour = 0; colour < 8; ++colour) {
     if (v->nquad[colour] == 0) continue;

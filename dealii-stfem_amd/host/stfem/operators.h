@@ -304,6 +304,22 @@ public:
     if (rc != STFEM_OK) throw Error(rc, std::string("PreconditionVanka::vmult: ") + stfem_vanka_last_error());
     compress_add(*ctx_, dst.handle(), stream); // partitioned: the interface planes hold partial sums (dst.compress(add) in the reference)
   }
+  // dst = (accumulate ? dst : 0) + omega * vmult(src): the step of PreconditionRelaxation (stmg.h:1199-1238), fused into the
+  // smoother's scatter (stfem_vanka_step).  On a slab of a partitioned mesh the partial sums of the interface planes have to be
+  // completed before they may be added to dst: there the update stays a pass of its own.
+  void step(BlockVectorType &dst, double omega, bool accumulate, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    const bool partitioned = ctx_->lower_rank >= 0 || ctx_->upper_rank >= 0;
+    if (partitioned && accumulate) {
+      if (!tmp_.handle() || tmp_.n_blocks() != dst.n_blocks()) tmp_.reinit(ctx_, dst.n_blocks());
+      vmult(tmp_, src, stream);
+      check(stfem_vector_axpby(ctx_->h, omega, tmp_.handle(), 1.0, dst.handle(), stream), "stfem_vector_axpby");
+      return;
+    }
+    const int rc = stfem_vanka_step(v_.get(), dst.handle(), omega, accumulate ? 1 : 0, src.handle(), stream);
+    if (rc != STFEM_OK) throw Error(rc, std::string("PreconditionVanka::step: ") + stfem_vanka_last_error());
+    compress_add(*ctx_, dst.handle(), stream);
+  }
   void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
   void clear() { v_.reset(); }
   int n_classes() const { return stfem_vanka_n_classes(v_.get()); }
@@ -311,6 +327,7 @@ public:
 private:
   std::shared_ptr<Context> ctx_;
   std::shared_ptr<stfem_vanka> v_;
+  mutable BlockVectorType tmp_;
 };
 
 // include/operators.h:1953-2050 PDE<>: the nonlinear-solver face of an operator.  residual = rhs - form(src);

@@ -102,17 +102,12 @@ public:
   {}
   void vmult(BlockVectorT<Number> &dst, const BlockVectorT<Number> &src, void *stream = nullptr) const
   {
-    if (!tmp.handle()) {
-      A.initialize_dof_vector(tmp);
-      A.initialize_dof_vector(res);
-    }
-    P.vmult(dst, src, stream);
-    axpby(0.0, dst, omega, dst, stream);
+    if (!res.handle() && n_iterations > 1) A.initialize_dof_vector(res);
+    P.step(dst, omega, false, src, stream); // dst = omega P^-1 src (scaling and update ride in the smoother's scatter)
     for (unsigned it = 1; it < n_iterations; ++it) {
       A.vmult(res, dst, stream);
       axpby(1.0, src, -1.0, res, stream); // res = src - A dst
-      P.vmult(tmp, res, stream);
-      axpby(omega, tmp, 1.0, dst, stream);
+      P.step(dst, omega, true, res, stream);
     }
   }
 
@@ -121,7 +116,7 @@ private:
   const PreconditionVanka<Number> &P;
   double omega;
   unsigned n_iterations;
-  mutable BlockVectorT<Number> tmp, res;
+  mutable BlockVectorT<Number> res;
 };
 
 // deal.II SolverFGMRES with ReductionControl(max_steps, abs_tol, reduce) as the reference sets it up

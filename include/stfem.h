@@ -307,6 +307,9 @@ int stfem_vanka_n_classes(const stfem_vanka *v); /* distinct cell blocks held */
 /* diagnostics: {row tiles (16 rows) per workgroup, parts per cell block} */
 int stfem_vanka_plan(const stfem_vanka *v, int32_t out[2]);
 int stfem_vanka_vmult(stfem_vanka *v, stfem_vec *dst, const stfem_vec *src, void *stream);
+/* dst = (accumulate ? dst : 0) + omega * V src: the step x <- x + omega P^-1 r of PreconditionRelaxation around the smoother
+ * (include/stmg.h:1199-1238) fused into the smoother's scatter - no temporary vector, no separate update pass. */
+int stfem_vanka_step(stfem_vanka *v, stfem_vec *dst, double omega, int accumulate, const stfem_vec *src, void *stream);
 const char *stfem_vanka_last_error(void);
 
 /* Around the operator, for the slab driver (include/time_integrators.h, tests/tp_01.cc:382-400, 646-725,

@@ -156,3 +156,37 @@ def test_vanka_device_setup_equals_host_setup(number, monkeypatch):
         V.vmult(dst, src)
         out.append(dst.download())
     assert rel(out[0], out[1]) < (1e-11 if number == "double" else 1e-5)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("number", ["double", "float"])
+@pytest.mark.parametrize("distort", [0.0, 0.1])
+def test_vanka_relaxation_step(number, distort, scheme, monkeypatch):
+    """stfem_vanka_step: dst = (dst | 0) + omega * V src, the step of PreconditionRelaxation (stmg.h:1199-1238) fused into the
+    scatter, against vmult + a separate update; class blocks and one block per cell, both apply schemes."""
+    stfem = importlib.import_module("dealii-stfem_amd")
+    _scheme(monkeypatch, scheme)
+    p, nc = 2, (4, 3, 3)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    ctx = (stfem.MatrixFreeOperator(p, nc, vertices=stfem.mesh_vertices(nc, distort=distort, seed=5), number=number) if distort else
+           stfem.MatrixFreeOperator(p, nc, number=number))
+    V = stfem.PreconditionVanka(ctx, Alpha, Beta)
+    rng = np.random.default_rng(9)
+    f = (lambda a: a.astype(np.float32).astype(np.float64)) if number == "float" else (lambda a: a)
+    X, D0 = f(rng.uniform(-1, 1, (nb, ctx.n_dofs))), f(rng.uniform(-1, 1, (nb, ctx.n_dofs)))
+    src = stfem.BlockVector(ctx, nb).upload(X)
+    ref = stfem.BlockVector(ctx, nb)
+    V.vmult(ref, src)
+    Y = ref.download()
+    tol = 1e-13 if number == "double" else 2e-6
+    dst = stfem.BlockVector(ctx, nb).upload(D0)
+    V.step(dst, 0.7, False, src)
+    assert rel(dst.download(), 0.7 * Y) < tol
+    dst.upload(D0)
+    V.step(dst, 0.7, True, src)
+    got = dst.download()
+    assert rel(got, D0 + 0.7 * Y) < tol
+    dst.upload(D0)
+    V.step(dst, 0.7, True, src)
+    assert np.array_equal(dst.download(), got)
