@@ -365,10 +365,10 @@ int stfem_coefficient_per_cell(const int32_t ncell[3], const double *vertices, d
                                double c3, double distort_coeff, const int32_t subdivisions[3],
                                const double lower[3], const double upper[3], double *out);
 
-/* ---- Stokes two-field operator (BASELINE configs[4]; cell loop only: LoopType::Cell,
- * include/operators.h:1228-1229, i.e. no weak boundary ids and delta0 = 0; the Nitsche / outflow /
- * CIP face terms of operators.h:1577-1751 are not built).  Velocity FE_Q(2)^3, pressure FE_Q(1),
- * QGauss(3), MappingQ1 on the mesh of `mesh`; mesh->dirichlet_mask constrains the velocity
+/* ---- Stokes two-field operator (BASELINE configs[4]): the cell loop (LoopType::Cell, include/operators.h:1228-1229) and,
+ * after stfem_stokes_set_weak_boundaries below, the weak (Nitsche) boundary faces of operators.h:1662-1751; the CIP interior-face
+ * term (delta0 != 0, 1603-1638) and the convection modes are not built.  Velocity FE_Q(2)^3, pressure FE_Q(1) (stfem_stokes_create)
+ * or FE_DGP(1) (stfem_stokes_create_ex), QGauss(3), MappingQ1 on the mesh of `mesh`; mesh->dirichlet_mask constrains the velocity
  * (homogeneous), the pressure is unconstrained.  fp64.
  * Layout: a velocity vector is 3 * n_velocity_dofs doubles, component-major, every component in
  * the scalar FE_Q(2) numbering of this header; a pressure vector is n_pressure_dofs doubles in
