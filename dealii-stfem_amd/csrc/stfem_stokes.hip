@@ -919,6 +919,10 @@ struct stfem_stokes_ctx {
   // and the 1D tables of the coupling kernels
   stfem_ctx *scalar = nullptr;
   CouplingParams coupling;
+  // the divergence kernel reads the sources and writes the pressure destinations only: it runs beside the velocity sweep on a
+  // stream of the context's own, forked from and joined to the caller's stream with two events
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int weak_mask = 0, outflow_mask = 0;
   double penalty1 = 20.0, penalty2 = 10.0;
   BoundaryParams bnd;
@@ -928,6 +932,12 @@ struct stfem_stokes_ctx {
 };
 
 static thread_local char g_stokes_err[256] = "";
+static int stokes_lowest_priority()
+{
+  int lo = 0, hi = 0; // (numerically highest value = lowest priority)
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return lo;
+}
 #define STOKES_TRY(call)                                                   \
   do {                                                                     \
     hipError_t e_ = (call);                                                \
@@ -1043,6 +1053,13 @@ int stfem_stokes_create_ex(const stfem_mesh_desc *mesh, int velocity_degree, int
       stfem_space_desc sd{2, 3, 1, 0};
       const int rc = stfem_ctx_create(&md, &sd, &c->scalar);
       if (rc != STFEM_OK) c->scalar = nullptr; // (the cell kernel serves then)
+      else if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, stokes_lowest_priority()) != hipSuccess ||
+               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->side) (void)hipStreamDestroy(c->side);
+        c->side = nullptr; // (the divergence kernel then follows the sweep on the caller's stream)
+      }
     }
     CouplingParams &k = c->coupling;
     k.ncx = c->nc[0]; k.ncy = c->nc[1]; k.ncz = c->nc[2];
@@ -1075,6 +1092,9 @@ void stfem_stokes_destroy(stfem_stokes_ctx *c)
   if (c->d_vertices) (void)hipFree(c->d_vertices);
   if (c->d_g) (void)hipFree(c->d_g);
   if (c->scalar) stfem_ctx_destroy(c->scalar);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -1158,6 +1178,45 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
       wM[o][q] = prm.nsrc > 1 ? prm.fM[o][q] : prm.wM[o];
     }
   }
+  // ---- the coupling, in gather form: parameters
+  bool k_u = false, k_p = false;
+  for (int o = 0; o < nout; ++o)
+    for (int q = 0; q < nsrc; ++q) {
+      k_u = k_u || (prm.out_u[o] && wKu[o][q] != 0.0 && ps[q]);
+      k_p = k_p || (prm.out_p[o] && wKp[o][q] != 0.0);
+    }
+  CouplingParams k = c->coupling;
+  k.nsrc = nsrc; k.nout = nout;
+  for (int q = 0; q < nsrc; ++q) { k.u[q] = us[q]; k.p[q] = ps[q]; }
+  for (int o = 0; o < nout; ++o) {
+    k.out_u[o] = prm.out_u[o]; k.out_p[o] = prm.out_p[o];
+    k.store_p[o] = prm.store_p[o];
+    for (int q = 0; q < nsrc; ++q) { k.wKu[o][q] = ps[q] ? wKu[o][q] : 0.0; k.wKp[o][q] = wKp[o][q]; }
+  }
+  (void)hipGetLastError();
+#define STOKES_COUPLING_LAUNCH(KERN, NS_, NO_, GRID, ...)                                                          \
+  do {                                                                                                             \
+    if (k.pdg) hipLaunchKernelGGL((stokes_##KERN##_kernel<NS_, NO_, true>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((stokes_##KERN##_kernel<NS_, NO_, false>), dim3(GRID), dim3(GRID##_threads), 0, st, __VA_ARGS__); \
+  } while (0)
+  const unsigned gu = (unsigned)((c->Nu + 255) / 256), gp = (unsigned)((c->Np + 255) / 256);
+  const unsigned gu_threads = 256, gp_threads = 256;
+  const int shape = (nsrc == 1 && nout == 1) ? 0 : ((nsrc <= 2 && nout <= 2) ? 1 : ((nsrc <= MAXSRC && nout <= 4) ? 2 : 3));
+  // ---- 2. out_p (=, +=) sum_q wKp B u_q, beside the velocity sweep (STFEM_STOKES_SERIAL=1: on the caller's stream, after it)
+  static const bool serial = [] { const char *e = getenv("STFEM_STOKES_SERIAL"); return e && atoi(e) != 0; }();
+  bool any_p = false;
+  for (int o = 0; o < nout; ++o) any_p = any_p || prm.out_p[o];
+  (void)k_p; // (a destination that is overwritten is written even with zero weights)
+  const bool forked = any_p && !serial && c->side;
+  auto launch_div = [&](hipStream_t st) {
+    if (shape == 0) STOKES_COUPLING_LAUNCH(div, 1, 1, gp, k, c->Np);
+    else if (shape == 1) STOKES_COUPLING_LAUNCH(div, 2, 2, gp, k, c->Np);
+    else if (shape == 2) STOKES_COUPLING_LAUNCH(div, MAXSRC, 4, gp, k, c->Np);
+    else STOKES_COUPLING_LAUNCH(div, MAXSRC, MAXOUT, gp, k, c->Np);
+  };
+  // (the fork point is here, before the sweep; the side stream's commands are enqueued after the sweep's so that the sweep's
+  // persistent workgroups - exactly the resident number - are placed first and the divergence kernel fills what is left)
+  if (forked) STOKES_TRY(hipEventRecord(c->ev_fork, st));
   // ---- 1. velocity blocks: out_u[o] (=, +=) sum_q (nu wKu K + wM M) u_q, component by component as scalar FE_Q(2) systems
   // (one launch with the three components as blocks when there is a single source and destination)
   for (int pass = 0; pass < 2; ++pass) { // destinations that are overwritten, then those that are accumulated into
@@ -1191,45 +1250,20 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
       }
     }
   }
-  // ---- 2., 3. the coupling, in gather form
-  bool k_u = false, k_p = false;
-  for (int o = 0; o < nout; ++o)
-    for (int q = 0; q < nsrc; ++q) {
-      k_u = k_u || (prm.out_u[o] && wKu[o][q] != 0.0 && ps[q]);
-      k_p = k_p || (prm.out_p[o] && wKp[o][q] != 0.0);
-    }
-  CouplingParams k = c->coupling;
-  k.nsrc = nsrc; k.nout = nout;
-  for (int q = 0; q < nsrc; ++q) { k.u[q] = us[q]; k.p[q] = ps[q]; }
-  for (int o = 0; o < nout; ++o) {
-    k.out_u[o] = prm.out_u[o]; k.out_p[o] = prm.out_p[o];
-    k.store_p[o] = prm.store_p[o];
-    for (int q = 0; q < nsrc; ++q) { k.wKu[o][q] = ps[q] ? wKu[o][q] : 0.0; k.wKp[o][q] = wKp[o][q]; }
+  if (forked) {
+    STOKES_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    launch_div(c->side);
+    STOKES_TRY(hipEventRecord(c->ev_join, c->side));
   }
-  (void)hipGetLastError();
-#define STOKES_COUPLING_LAUNCH(KERN, NS_, NO_, GRID, ...)                                                          \
-  do {                                                                                                             \
-    if (k.pdg) hipLaunchKernelGGL((stokes_##KERN##_kernel<NS_, NO_, true>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);  \
-    else hipLaunchKernelGGL((stokes_##KERN##_kernel<NS_, NO_, false>), dim3(GRID), dim3(GRID##_threads), 0, st, __VA_ARGS__); \
-  } while (0)
-  const unsigned gu = (unsigned)((c->Nu + 255) / 256), gp = (unsigned)((c->Np + 255) / 256);
-  const unsigned gu_threads = 256, gp_threads = 256;
-  const int shape = (nsrc == 1 && nout == 1) ? 0 : ((nsrc <= 2 && nout <= 2) ? 1 : ((nsrc <= MAXSRC && nout <= 4) ? 2 : 3));
+  // ---- 3. out_u -= sum_q wKu B^T p_q
   if (k_u) {
     if (shape == 0) STOKES_COUPLING_LAUNCH(grad, 1, 1, gu, k);
     else if (shape == 1) STOKES_COUPLING_LAUNCH(grad, 2, 2, gu, k);
     else if (shape == 2) STOKES_COUPLING_LAUNCH(grad, MAXSRC, 4, gu, k);
     else STOKES_COUPLING_LAUNCH(grad, MAXSRC, MAXOUT, gu, k);
   }
-  bool any_p = false;
-  for (int o = 0; o < nout; ++o) any_p = any_p || prm.out_p[o];
-  (void)k_p; // (a destination that is overwritten is written even with zero weights)
-  if (any_p) {
-    if (shape == 0) STOKES_COUPLING_LAUNCH(div, 1, 1, gp, k, c->Np);
-    else if (shape == 1) STOKES_COUPLING_LAUNCH(div, 2, 2, gp, k, c->Np);
-    else if (shape == 2) STOKES_COUPLING_LAUNCH(div, MAXSRC, 4, gp, k, c->Np);
-    else STOKES_COUPLING_LAUNCH(div, MAXSRC, MAXOUT, gp, k, c->Np);
-  }
+  if (forked) STOKES_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+  else if (any_p) launch_div(st);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     snprintf(g_stokes_err, sizeof(g_stokes_err), "stokes coupling kernels: %s", hipGetErrorString(e));

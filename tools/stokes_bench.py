@@ -26,7 +26,7 @@ for d in range(nt):
 for _ in range(3):
     op.st_vmult(Alpha, Beta, 1, nt, dst, src)
 dst[0].download()
-reps = 20
+reps = int(os.environ.get('STOKES_BENCH_REPS', '100'))
 t0 = time.perf_counter()
 for _ in range(reps):
     op.st_vmult(Alpha, Beta, 1, nt, dst, src)
