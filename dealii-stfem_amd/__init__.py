@@ -168,6 +168,12 @@ SIGNATURES = {
     "stfem_stokes_n_face_points": (C.c_int64, [_vp]),
     "stfem_stokes_face_points": (C.c_int, [_vp, _dp]),
     "stfem_stokes_nitsche_rhs": (C.c_int, [_vp, _dp, _vp, _vp, _vp]),
+    "stfem_stokes_vanka_create": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32), _dp, _dp, C.POINTER(_vp)]),
+    "stfem_stokes_vanka_destroy": (None, [_vp]),
+    "stfem_stokes_vanka_n_classes": (C.c_int, [_vp]),
+    "stfem_stokes_vanka_vmult": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "stfem_stokes_vanka_step": (C.c_int, [_vp, C.POINTER(_vp), C.c_double, C.c_int, C.POINTER(_vp), _vp]),
+    "stfem_stokes_vanka_last_error": (C.c_char_p, []),
     "stfem_strerror": (C.c_char_p, [C.c_int]),
     "stfem_last_hip_error": (C.c_char_p, []),
     "stfem_last_kernel_name": (C.c_char_p, [_vp]),
@@ -761,6 +767,45 @@ class StokesMatrixFreeOperator:
                                                      _p(g), _p(z), d, getattr(src_u, "ptr", src_u),
                                                      getattr(src_p, "ptr", src_p), stream),
                "stfem_stokes_st_vmult_slice_add")
+
+
+class StokesPreconditionVanka:
+    """PreconditionVanka over a two-variable BlockSlice (stmg.h:626-738, 832-872, as tests/tp_03stokes.cc:714-726 creates it).
+    block_variable[i] = 0 (velocity) / 1 (pressure) for the blocks in BlockSlice order; Alpha, Beta: the matrices of
+    get_fe_time_weights_stokes."""
+
+    def __init__(self, op, block_variable, Alpha, Beta):
+        self.op = op
+        self.nb = len(block_variable)
+        bv = (C.c_int32 * self.nb)(*[int(v) for v in block_variable])
+        A = np.ascontiguousarray(Alpha, dtype=np.float64); B = np.ascontiguousarray(Beta, dtype=np.float64)
+        assert A.shape == (self.nb, self.nb) and B.shape == (self.nb, self.nb)
+        h = _vp()
+        rc = lib().stfem_stokes_vanka_create(op._h, self.nb, bv, _p(A), _p(B), C.byref(h))
+        if rc != 0:
+            raise StfemError(rc, "stfem_stokes_vanka_create: " + lib().stfem_stokes_vanka_last_error().decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().stfem_stokes_vanka_destroy(self._h)
+            self._h = None
+
+    @property
+    def n_classes(self):
+        return lib().stfem_stokes_vanka_n_classes(self._h)
+
+    def step(self, dst_blocks, omega, accumulate, src_blocks, stream=None):
+        d = (_vp * self.nb)(*[getattr(v, "ptr", v) for v in dst_blocks])
+        s_ = (_vp * self.nb)(*[getattr(v, "ptr", v) for v in src_blocks])
+        rc = lib().stfem_stokes_vanka_step(self._h, d, omega, int(bool(accumulate)), s_, stream)
+        if rc != 0:
+            raise StfemError(rc, "stfem_stokes_vanka_step: " + lib().stfem_stokes_vanka_last_error().decode())
+
+    def vmult(self, dst_blocks, src_blocks, stream=None):
+        self.step(dst_blocks, 1.0, False, src_blocks, stream)
+
+    smooth = vmult
 
 
 class StokesVector:

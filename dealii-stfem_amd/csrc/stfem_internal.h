@@ -51,3 +51,12 @@ struct stfem_vec {
 // stfem_capi.hip: (re)builds the per-quadrature-point metric records [cell][qz][qy][qx][8] =
 // (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad) with the coefficient tables in force; element type = the context's Number
 int stfem_internal_metric(stfem_ctx *c, const void **metric, void *stream);
+
+// stfem_stokes.hip: what stfem_stokes_vanka.hip needs to know about a Stokes context
+struct stfem_stokes_desc {
+  int device, cart, pspace, dmask, weak_mask, outflow_mask;
+  int nc[3], ndu[3], ndp[3];
+  long long Nu, Np;
+  double lower[3], upper[3], nu, penalty1, penalty2;
+};
+int stfem_stokes_internal_desc(const stfem_stokes_ctx *c, stfem_stokes_desc *out);

@@ -17,8 +17,7 @@
 // integration are sum-factorised (three 1D stages each, see stokes_cell_kernel); the MappingQ1
 // Jacobian is evaluated on the fly from the eight cell vertices (24 doubles per cell instead of a
 // stored metric), or is a constant diagonal on axis-aligned boxes.
-#include "../../include/stfem.h"
-#include "host_tables.h"
+#include "stfem_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1097,6 +1096,22 @@ void stfem_stokes_destroy(stfem_stokes_ctx *c)
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
+
+} // extern "C"
+int stfem_stokes_internal_desc(const stfem_stokes_ctx *c, stfem_stokes_desc *d)
+{
+  if (!c || !d) return STFEM_ERR_INVALID_ARGUMENT;
+  d->device = c->device; d->cart = c->base.cart; d->pspace = c->pspace; d->dmask = c->dmask;
+  d->weak_mask = c->weak_mask; d->outflow_mask = c->outflow_mask;
+  for (int k = 0; k < 3; ++k) {
+    d->nc[k] = c->nc[k]; d->ndu[k] = c->ndu[k]; d->ndp[k] = c->ndp[k];
+    d->lower[k] = c->h_vertices[k];
+    d->upper[k] = c->h_vertices[c->h_vertices.size() - 3 + k];
+  }
+  d->Nu = c->Nu; d->Np = c->Np; d->nu = c->nu; d->penalty1 = c->penalty1; d->penalty2 = c->penalty2;
+  return STFEM_OK;
+}
+extern "C" {
 
 int64_t stfem_stokes_n_velocity_dofs(const stfem_stokes_ctx *c) { return c ? c->Nu : 0; }
 int64_t stfem_stokes_n_pressure_dofs(const stfem_stokes_ctx *c) { return c ? c->Np : 0; }

@@ -440,6 +440,24 @@ int stfem_stokes_face_points(const stfem_stokes_ctx *ctx, double *out);
 int stfem_stokes_nitsche_rhs(stfem_stokes_ctx *ctx, const double *g_at_face_points, double *dst_u, double *dst_p, void *stream);
 const char *stfem_stokes_last_hip_error(void);
 
+/* PreconditionVanka over a BlockSlice with two variables (reference include/stmg.h:626-738, 832-872, as tests/tp_03stokes.cc:537-540,
+ * 714-726 creates it: K_mask empty, M_mask(0, 0) only): per cell the inverse of
+ *     B((i, k), (j, l)) = valence(k) * (Alpha(i, j) K_{iv,jv}(k, l) + [iv = jv = velocity] Beta(i, j) M(k, l)),
+ * i, j = blocks of the BlockSlice, block_variable[i] = 0 (velocity) / 1 (pressure), K = the assembled Stokes matrix of the context
+ * (weak boundary faces included; strong velocity constraints: row and column dropped, diagonal kept), M = the vector mass;
+ * vmult / step: dst = (accumulate ? dst : 0) + omega * sum over cells of scatter(B_c^-1 gather(src)), blocks in BlockSlice order
+ * (at most 8; velocity blocks 3 * n_velocity_dofs doubles, pressure blocks n_pressure_dofs).  Axis-aligned uniform meshes (<= 27
+ * distinct blocks, read off the operator applied to unit vectors); general meshes: STFEM_ERR_UNSUPPORTED.  fp64. */
+typedef struct stfem_stokes_vanka stfem_stokes_vanka;
+int stfem_stokes_vanka_create(stfem_stokes_ctx *ctx, int n_blocks, const int32_t *block_variable, const double *Alpha, const double *Beta,
+                              stfem_stokes_vanka **out);
+void stfem_stokes_vanka_destroy(stfem_stokes_vanka *v);
+int stfem_stokes_vanka_n_classes(const stfem_stokes_vanka *v);
+int stfem_stokes_vanka_vmult(stfem_stokes_vanka *v, double *const *dst_blocks, const double *const *src_blocks, void *stream);
+int stfem_stokes_vanka_step(stfem_stokes_vanka *v, double *const *dst_blocks, double omega, int accumulate, const double *const *src_blocks,
+                            void *stream);
+const char *stfem_stokes_vanka_last_error(void);
+
 const char *stfem_strerror(int status);
 /* text of the last failing HIP call on this thread ("" if none) */
 const char *stfem_last_hip_error(void);
