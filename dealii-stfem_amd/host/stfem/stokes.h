@@ -293,4 +293,45 @@ private:
   BlockSlice blk_slice;
 };
 
+// PreconditionVanka in its block form (include/stmg.h:626-738, 832-872) as tests/tp_03stokes.cc:537-540, 714-726 creates it for the
+// Stokes levels: the assembled Stokes and mass matrices restricted to every cell's velocity and pressure DoFs, combined with
+// Alpha / Beta over the blocks of the BlockSlice (K_mask empty, M_mask(0, 0) only), inverted.  The assembled matrices and DoF
+// handlers of the reference's constructor are not needed: the blocks follow from the operator (stfem_stokes_vanka_create).
+template <typename Number> class PreconditionVankaStokes {
+  static_assert(std::is_same<Number, double>::value, "fp64");
+
+public:
+  using BlockVectorType = std::vector<StokesVector>;
+  template <int dim>
+  PreconditionVankaStokes(const StokesMatrixFreeOperator<dim, Number> &K, const FullMatrix<Number> &Alpha, const FullMatrix<Number> &Beta,
+                          const BlockSlice &blk_slice)
+    : nb_(blk_slice.n_blocks())
+  {
+    if (Alpha.m() != nb_ || Alpha.n() != nb_ || Beta.m() != nb_ || Beta.n() != nb_) throw std::invalid_argument("Alpha/Beta do not match the block slice");
+    std::vector<int32_t> var(nb_);
+    for (unsigned i = 0; i < nb_; ++i) var[i] = int32_t(blk_slice.decompose(i)[1]);
+    stfem_stokes_vanka *v = nullptr;
+    const int rc = stfem_stokes_vanka_create(K.handle(), int(nb_), var.data(), Alpha.data(), Beta.data(), &v);
+    if (rc != STFEM_OK) throw Error(rc, std::string("stfem_stokes_vanka_create: ") + stfem_stokes_vanka_last_error());
+    v_.reset(v, stfem_stokes_vanka_destroy);
+  }
+  void vmult(BlockVectorType &dst, const BlockVectorType &src, void *stream = nullptr) const { step(dst, 1.0, false, src, stream); }
+  void smooth(BlockVectorType &u, const BlockVectorType &rhs) const { vmult(u, rhs); }
+  // dst = (accumulate ? dst : 0) + omega * vmult(src): the step of the PreconditionRelaxation around the smoother (stmg.h:1199-1238)
+  void step(BlockVectorType &dst, double omega, bool accumulate, const BlockVectorType &src, void *stream = nullptr) const
+  {
+    if (dst.size() != nb_ || src.size() != nb_) throw Error(STFEM_ERR_SHAPE_MISMATCH, "PreconditionVankaStokes::vmult");
+    std::vector<double *> d(nb_);
+    std::vector<const double *> s(nb_);
+    for (unsigned i = 0; i < nb_; ++i) { d[i] = dst[i].data(); s[i] = src[i].data(); }
+    const int rc = stfem_stokes_vanka_step(v_.get(), d.data(), omega, accumulate ? 1 : 0, s.data(), stream);
+    if (rc != STFEM_OK) throw Error(rc, std::string("PreconditionVankaStokes::vmult: ") + stfem_stokes_vanka_last_error());
+  }
+  int n_classes() const { return stfem_stokes_vanka_n_classes(v_.get()); }
+
+private:
+  unsigned nb_;
+  std::shared_ptr<stfem_stokes_vanka> v_;
+};
+
 } // namespace stfem

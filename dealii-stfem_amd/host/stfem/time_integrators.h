@@ -122,9 +122,15 @@ private:
 // deal.II SolverFGMRES with ReductionControl(max_steps, abs_tol, reduce) as the reference sets it up
 // (time_integrators.h:57-60: 200 steps, 1e-12 absolute, gmres_tolerance relative, restart 100):
 // right-preconditioned flexible GMRES, modified Gram-Schmidt, Givens rotations.
-template <typename Number> class SolverFGMRES {
+// VectorType: BlockVectorT<Number>, or any type with the free functions axpby, norm, orthogonalize and reinit_like
+// (host/stfem/stokes_solver.h: the two-variable block vector of the Stokes systems).
+template <typename Number> inline void reinit_like(BlockVectorT<Number> &v, const BlockVectorT<Number> &x)
+{
+  if (!v.handle()) v.reinit(x.context(), x.n_blocks());
+}
+template <typename Number, typename VectorType = BlockVectorT<Number>> class SolverFGMRES {
 public:
-  using V = BlockVectorT<Number>;
+  using V = VectorType;
   SolverFGMRES(unsigned max_steps, double abs_tol, double reduce, unsigned restart = 100)
     : max_steps(max_steps), abs_tol(abs_tol), reduce(reduce), restart(restart)
   {}
@@ -138,10 +144,7 @@ public:
     steps = 0;
     V r;
     A.initialize_dof_vector(r);
-    const unsigned nb = x.n_blocks();
-    auto fresh = [&](V &v) {
-      if (!v.handle()) v.reinit(x.context(), nb);
-    };
+    auto fresh = [&](V &v) { reinit_like(v, x); };
     double tol = abs_tol;
     bool first = true;
     while (true) {

@@ -178,3 +178,208 @@ def heat_convergence_row_3d(ttype, k, refinement, nsteps=2, frequency=1.0, wave=
         prev = x[-1]
         time += nsteps * tau
     return acc_l8, np.sqrt(acc_l2), np.sqrt(acc_h1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Instationary Stokes in 3D (BASELINE configs[4]: FE_Q(2)^3 x FE_Q(1), cG / dG in time).  The recipe of tests/tp_03stokes.cc, which
+# tests/test_tp03stokes_reference.py pins to the reference's own 2D tables, in the dimension the HIP path works in:
+#   operators.h:825-867 SystemMatrixStokes, fe_time.h:1242-1285 get_fe_time_weights_stokes, tp_03stokes.cc:238-246 right-hand-side
+#   matrices, time_integrators.h:73-111 assemble_force (velocity only), tp_03stokes.cc:1047-1062 pressure shifted to zero mean,
+#   exact_solution.h:503-649 ErrorCalculator (QGauss(k + 1) in time, QGauss(3) per direction for u, QGauss(2) for p).
+# The reference's exact solution (exact_solution.h:199-325) is two-dimensional; this one is its 3D analogue: the velocity is the curl of
+# psi e_z, psi = sin t (sin pi x sin pi y sin pi z)^2 (divergence-free, zero on the whole boundary), the pressure sin t cos pi x cos pi y
+# cos pi z (zero mean), the force f = u_t - nu laplace u + grad p.
+PI = np.pi
+
+
+def stokes3d_exact_u(X, Y, Z, t):
+    A = lambda s: np.sin(PI * s) ** 2               # noqa: E731
+    B = lambda s: np.sin(PI * s) * np.cos(PI * s)   # noqa: E731
+    st = np.sin(t)
+    return (2 * PI * st * A(X) * B(Y) * A(Z), -2 * PI * st * B(X) * A(Y) * A(Z), np.zeros_like(X + Y + Z))
+
+
+def stokes3d_exact_grad_u(X, Y, Z, t):
+    A = lambda s: np.sin(PI * s) ** 2                     # noqa: E731
+    dA = lambda s: PI * np.sin(2 * PI * s)                # noqa: E731
+    B = lambda s: 0.5 * np.sin(2 * PI * s)                # noqa: E731
+    dB = lambda s: PI * np.cos(2 * PI * s)                # noqa: E731
+    c = 2 * PI * np.sin(t)
+    z = np.zeros_like(X + Y + Z)
+    return ((c * dA(X) * B(Y) * A(Z), c * A(X) * dB(Y) * A(Z), c * A(X) * B(Y) * dA(Z)),
+            (-c * dB(X) * A(Y) * A(Z), -c * B(X) * dA(Y) * A(Z), -c * B(X) * A(Y) * dA(Z)),
+            (z, z, z))
+
+
+def stokes3d_exact_p(X, Y, Z, t):
+    return np.sin(t) * np.cos(PI * X) * np.cos(PI * Y) * np.cos(PI * Z)
+
+
+def stokes3d_force(X, Y, Z, t, nu):
+    A = lambda s: np.sin(PI * s) ** 2                     # noqa: E731
+    d2A = lambda s: 2 * PI * PI * np.cos(2 * PI * s)      # noqa: E731
+    B = lambda s: 0.5 * np.sin(2 * PI * s)                # noqa: E731
+    d2B = lambda s: -4 * PI * PI * B(s)                   # noqa: E731
+    st, ct = np.sin(t), np.cos(t)
+    lap1 = d2A(X) * B(Y) * A(Z) + A(X) * d2B(Y) * A(Z) + A(X) * B(Y) * d2A(Z)
+    lap2 = d2B(X) * A(Y) * A(Z) + B(X) * d2A(Y) * A(Z) + B(X) * A(Y) * d2A(Z)
+    sx, sy, sz, cx, cy, cz = np.sin(PI * X), np.sin(PI * Y), np.sin(PI * Z), np.cos(PI * X), np.cos(PI * Y), np.cos(PI * Z)
+    f1 = 2 * PI * (ct * A(X) * B(Y) * A(Z) - nu * st * lap1) - PI * st * sx * cy * cz
+    f2 = -2 * PI * (ct * B(X) * A(Y) * A(Z) - nu * st * lap2) - PI * st * cx * sy * cz
+    f3 = -PI * st * cx * cy * sz + 0.0 * (X + Y + Z)
+    return f1, f2, f3
+
+
+def stokes_convergence_row_3d(ttype, k, refinement, nu=1.0):
+    """(u: L-inf L-inf, L2 L2, L2 H1-semi; p: L2 L2) of the solution above on the unit cube, FE_Q(2)^3 x FE_Q(1) x {cG, dG}(k), 2^refinement
+    cells per direction, tau = 2^-(refinement + 1), homogeneous Dirichlet velocity on the whole boundary, one time step per solve."""
+    n = 2 ** refinement
+    h = 1.0 / n
+    tau = 2.0 ** -(refinement + 1)
+    nc = (n, n, n)
+    verts = np.array([[i * h, j * h, kk * h] for kk in range(n + 1) for j in range(n + 1) for i in range(n + 1)], dtype=float)
+    so = o.StokesOracle(nc, verts, 0, nu)
+    Nu, Np = so.n_u, so.n_p
+    ndu, ndp = 2 * n + 1, n + 1
+    ntot = 3 * Nu + Np
+    K = np.zeros((ntot, ntot))
+    M = np.zeros((3 * Nu, 3 * Nu))
+    e = np.zeros(ntot)
+    for j in range(ntot):
+        e[j] = 1.0
+        ou, op = so.apply(e[:3 * Nu], e[3 * Nu:], 1.0, 0.0)
+        K[:3 * Nu, j], K[3 * Nu:, j] = ou.reshape(-1), op
+        if j < 3 * Nu:
+            M[:, j] = so.apply(e[:3 * Nu], np.zeros(Np), 0.0, 1.0)[0].reshape(-1)
+        e[j] = 0.0
+    iu = np.arange(ndu ** 3).reshape(ndu, ndu, ndu)
+    free1 = iu[1:-1, 1:-1, 1:-1].ravel()
+    free = np.concatenate([c * Nu + free1 for c in range(3)])
+    nf = len(free)
+    pidx = 3 * Nu + np.arange(Np)
+    KS_uu, Bt, Bm = K[np.ix_(free, free)], K[np.ix_(free, pidx)], K[np.ix_(pidx, free)]   # nu K, -B^T, B
+    MM = M[np.ix_(free, free)]
+    A1, B1, G1, Z1 = o.time_weights(ttype, k, tau, 1)
+    nt = A1.shape[0]
+    NU, NP = nf, Np
+    N = nt * (NU + NP)
+    ub = lambda a: slice(a * NU, (a + 1) * NU)                     # noqa: E731
+    pb = lambda a: slice(nt * NU + a * NP, nt * NU + (a + 1) * NP)  # noqa: E731
+    sysm = np.zeros((N, N))
+    for a in range(nt):
+        for b in range(nt):
+            sysm[ub(a), ub(b)] += A1[a, b] * KS_uu + B1[a, b] * MM
+            sysm[ub(a), pb(b)] += A1[a, b] * Bt
+            sysm[pb(a), ub(b)] += A1[a, b] * Bm
+    keep = np.ones(N, dtype=bool)
+    for a in range(nt):
+        keep[nt * NU + a * NP] = False       # the pressure is determined up to a constant: pin one value, shift to zero mean afterwards
+    import scipy.linalg
+    lu = scipy.linalg.lu_factor(sysm[np.ix_(keep, keep)])
+    # right-hand-side matrices (tests/tp_03stokes.cc:243-244): cG: Gamma on K_S (both variables), Zeta on M; dG: Gamma on M
+    if ttype == o.CGP:
+        rKu, rKp, rM = G1[:, 0], G1[:, 0], Z1[:, 0]
+    else:
+        rKu, rKp, rM = np.zeros(nt), np.zeros(nt), G1[:, 0]
+    Su, _ = o.shape_tables(2)
+    xq, wq = o.gauss(3)
+
+    def load_vector(t):
+        F = np.zeros((3, ndu, ndu, ndu))
+        W = h ** 3 * np.einsum("i,j,k->ijk", wq, wq, wq)
+        for cz in range(n):
+            for cy in range(n):
+                for cx in range(n):
+                    X, Y, Zc = h * (cx + xq)[None, None, :], h * (cy + xq)[None, :, None], h * (cz + xq)[:, None, None]
+                    f = stokes3d_force(X, Y, Zc, t, nu)
+                    for c in range(3):
+                        F[c, 2 * cz:2 * cz + 3, 2 * cy:2 * cy + 3, 2 * cx:2 * cx + 3] += np.einsum("zyx,za,yb,xc->abc", W * f[c], Su, Su, Su)
+        return F.reshape(3 * Nu)[free]
+
+    tq_int = o.gauss_radau_right(k + 1) if ttype == o.DG else o.gauss_lobatto(k + 1)
+    et, ewt = o.gauss(k + 1)
+    Ltime, _ = lagrange_eval(tq_int, et)
+    eu, ewu = o.gauss(3)
+    ep, ewp = o.gauss(2)
+    Eu, dEu = lagrange_eval(o.gauss_lobatto(3), eu)
+    Ep, _ = lagrange_eval(o.gauss_lobatto(2), ep)
+
+    def errors_u(uf, t):
+        U = np.zeros(3 * Nu)
+        U[free] = uf
+        U = U.reshape(3, ndu, ndu, ndu)
+        l2 = h1 = l8 = 0.0
+        W = h ** 3 * np.einsum("i,j,k->ijk", ewu, ewu, ewu)
+        for cz in range(n):
+            for cy in range(n):
+                for cx in range(n):
+                    X, Y, Zc = h * (cx + eu)[None, None, :], h * (cy + eu)[None, :, None], h * (cz + eu)[:, None, None]
+                    ue, ge = stokes3d_exact_u(X, Y, Zc, t), stokes3d_exact_grad_u(X, Y, Zc, t)
+                    for c in range(3):
+                        loc = U[c, 2 * cz:2 * cz + 3, 2 * cy:2 * cy + 3, 2 * cx:2 * cx + 3]
+                        uh = np.einsum("ac,bd,ef,cdf->abe", Eu, Eu, Eu, loc)
+                        ux = np.einsum("ac,bd,ef,cdf->abe", Eu, Eu, dEu, loc) / h
+                        uy = np.einsum("ac,bd,ef,cdf->abe", Eu, dEu, Eu, loc) / h
+                        uz = np.einsum("ac,bd,ef,cdf->abe", dEu, Eu, Eu, loc) / h
+                        l2 += np.sum(W * (uh - ue[c]) ** 2)
+                        h1 += np.sum(W * ((ux - ge[c][0]) ** 2 + (uy - ge[c][1]) ** 2 + (uz - ge[c][2]) ** 2))
+                        l8 = max(l8, np.abs(uh - ue[c]).max())
+        return l2, l8, h1
+
+    def errors_p(pf, t):
+        P = pf.reshape(ndp, ndp, ndp)
+        l2 = 0.0
+        W = h ** 3 * np.einsum("i,j,k->ijk", ewp, ewp, ewp)
+        for cz in range(n):
+            for cy in range(n):
+                for cx in range(n):
+                    X, Y, Zc = h * (cx + ep)[None, None, :], h * (cy + ep)[None, :, None], h * (cz + ep)[:, None, None]
+                    ph = np.einsum("ac,bd,ef,cdf->abe", Ep, Ep, Ep, P[cz:cz + 2, cy:cy + 2, cx:cx + 2])
+                    l2 += np.sum(W * (ph - stokes3d_exact_p(X, Y, Zc, t)) ** 2)
+        return l2
+
+    # mean of a FE_Q(1) function: 1^T M_p p / |Omega| with the exact Q1 mass (trapezoid weights per direction)
+    w1 = np.full(ndp, h)
+    w1[0] = w1[-1] = h / 2
+    mean_w = np.einsum("i,j,k->ijk", w1, w1, w1).ravel()
+    prev_u, prev_p = np.zeros(NU), np.zeros(NP)
+    time = 0.0
+    acc_l2 = acc_h1 = acc_p = 0.0
+    acc_l8 = -1.0
+    while time < 1.0 - 1e-12:
+        rhs = np.zeros(N)
+        KSu = KS_uu @ prev_u + Bt @ prev_p
+        KSp = Bm @ prev_u
+        Mu = MM @ prev_u
+        for a in range(nt):
+            rhs[ub(a)] = rKu[a] * KSu + rM[a] * Mu
+            rhs[pb(a)] = rKp[a] * KSp
+        for j, xi in enumerate(tq_int):
+            F = load_vector(time + tau * xi)
+            if ttype == o.DG:
+                rhs[ub(j)] += A1[j, j] * F
+            elif j == 0:
+                for i in range(nt):
+                    rhs[ub(i)] += -G1[i, 0] * F
+            else:
+                rhs[ub(j - 1)] += A1[j - 1, j - 1] * F
+        sol = np.zeros(N)
+        sol[keep] = scipy.linalg.lu_solve(lu, rhs[keep])
+        xu = [sol[ub(a)] for a in range(nt)]
+        xp = [sol[pb(a)] - np.dot(mean_w, sol[pb(a)]) for a in range(nt)]
+        for q in range(k + 1):
+            if ttype == o.DG:
+                uf = sum(Ltime[q, i] * xu[i] for i in range(nt))
+                pf = sum(Ltime[q, i] * xp[i] for i in range(nt))
+            else:
+                uf = Ltime[q, 0] * prev_u + sum(Ltime[q, i] * xu[i - 1] for i in range(1, k + 1))
+                pf = Ltime[q, 0] * prev_p + sum(Ltime[q, i] * xp[i - 1] for i in range(1, k + 1))
+            t = time + tau * et[q]
+            l2, l8, h1 = errors_u(uf, t)
+            acc_l2 += tau * ewt[q] * l2
+            acc_h1 += tau * ewt[q] * h1
+            acc_l8 = max(acc_l8, l8)
+            acc_p += tau * ewt[q] * errors_p(pf, t)
+        prev_u, prev_p = xu[-1], xp[-1]
+        time += tau
+    return acc_l8, np.sqrt(acc_l2), np.sqrt(acc_h1), np.sqrt(acc_p)
