@@ -3,6 +3,7 @@
 // time integrator of include/time_integrators.h:30-336 with a velocity force, for FE_Q(2)^3 x FE_Q(1) (BASELINE configs[4]).
 // Control flow only: every vector operation, integral and operator application is a call into libstfem_hip.so.
 #pragma once
+#include "stmg.h"
 #include "stokes.h"
 #include "time_integrators.h"
 
@@ -136,6 +137,188 @@ private:
   unsigned n_iterations;
   mutable StokesBlockVector res;
 };
+
+template <typename System>
+double estimate_relaxation_stokes(const System &A, const PreconditionVankaStokes<double> &P, unsigned n_iterations = 20, double smoothing_range = 1.0);
+
+// The geometric multigrid of the reference's Stokes runs (tests/tp_03stokes.cc:283-290, 484-770: coarsening sequence in space from
+// MGTransferGlobalCoarseningTools::create_geometric_coarsening_sequence, one StokesMatrixFreeOperator / SystemMatrixStokes /
+// PreconditionVanka per level, MGTwoLevelBlockTransfer with one space transfer per variable; include/stmg.h:1160-1419: GMG with
+// Multigrid, MGSmootherPrecondition around PreconditionRelaxation(Vanka), MGCoarseGridApplySmoother, PreconditionMG) over the
+// C-ABI: the velocity components are transferred as FE_Q(2) functions with the constraints of both levels, the pressure as a
+// FE_Q(1) function (stfem_transfer_*), every level smooths with relaxation sweeps of the two-variable Vanka smoother.  Space levels
+// only (the temporal blocks are the same on every level).
+template <int dim> class GMGStokes {
+public:
+  struct AdditionalData {
+    unsigned smoothing_steps = 1;      // PreconditionerGMGAdditionalData::smoothing_steps
+    bool variable = true;              // MGSmootherPrecondition variable: 2^(max_level - level) steps on level `level`
+    unsigned smoothing_degree = 1;     // sweeps of PreconditionRelaxation per step
+    double relaxation = 0.0;           // its omega; 0: estimated per level (20 power iterations on P^-1 A), as the reference's default
+  };
+  // the finest mesh has mesh.ncell cells; level l < n_levels - 1 has them halved n_levels - 1 - l times
+  GMGStokes(const Mesh &mesh, unsigned n_levels, double viscosity, const FullMatrix<double> &Alpha, const FullMatrix<double> &Beta,
+            const BlockSlice &slice, const AdditionalData &data = AdditionalData(), const std::set<boundary_id> &weak_boundary_ids = {},
+            bool dg_pressure = false)
+    : data_(data), slice_(slice), Alpha_(Alpha), Beta_(Beta)
+  {
+    if (n_levels < 1) throw std::invalid_argument("GMGStokes: at least one level");
+    if (dg_pressure) throw Error(STFEM_ERR_UNSUPPORTED, "GMGStokes: FE_DGP pressure transfers are not built");
+    levels_.resize(n_levels);
+    for (unsigned l = 0; l < n_levels; ++l) {
+      Level &L = levels_[l];
+      L.mesh = mesh;
+      for (int d = 0; d < 3; ++d) {
+        const int f = 1 << (n_levels - 1 - l);
+        if (mesh.ncell[d] % f) throw std::invalid_argument("GMGStokes: the cell counts must be divisible by 2^(levels - 1)");
+        L.mesh.ncell[d] = mesh.ncell[d] / f;
+      }
+      L.K = std::make_unique<StokesMatrixFreeOperator<dim, double>>(L.mesh, 2, viscosity, weak_boundary_ids);
+      L.spaces = std::make_shared<StokesSpaces>(L.mesh);
+      L.A = std::make_unique<SystemMatrixStokes<dim, double>>(*L.K, Alpha_, Beta_, slice_);
+      L.system = std::make_unique<StokesSystem<dim, double>>(*L.A, L.spaces, L.K->handle(), slice_);
+      L.vanka = std::make_unique<PreconditionVankaStokes<double>>(*L.K, Alpha_, Beta_, slice_);
+      L.omega = data.relaxation != 0.0 ? data.relaxation : estimate_relaxation_stokes(*L.system, *L.vanka, 20, 1.0);
+      L.relax = std::make_unique<PreconditionRelaxationStokes<StokesSystem<dim, double>>>(*L.system, *L.vanka, L.omega, data.smoothing_degree);
+      L.system->initialize_dof_vector(L.defect);
+      L.system->initialize_dof_vector(L.solution);
+      L.system->initialize_dof_vector(L.t);
+      if (l > 0) {
+        L.tr_u = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q2, levels_[l - 1].spaces->q2);
+        L.tr_p = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q1, levels_[l - 1].spaces->q1);
+      }
+    }
+  }
+  const StokesSystem<dim, double> &finest_system() const { return *levels_.back().system; }
+  const StokesMatrixFreeOperator<dim, double> &finest_operator() const { return *levels_.back().K; }
+  const std::shared_ptr<StokesSpaces> &finest_spaces() const { return levels_.back().spaces; }
+  double relaxation(unsigned level) const { return levels_.at(level).omega; }
+  unsigned n_levels() const { return unsigned(levels_.size()); }
+
+  // PreconditionMG::vmult: copy_to_mg, one V-cycle from zero, copy_from_mg
+  void vmult(StokesBlockVector &dst, const StokesBlockVector &src, void * = nullptr) const
+  {
+    TraceRange scope("gmg");
+    const unsigned top = unsigned(levels_.size()) - 1;
+    // (the caller's vectors may live on contexts of their own for the same mesh: view their blocks through this level's spaces)
+    for (unsigned b = 0; b < slice_.n_blocks(); ++b) axpby(1.0, foreign_view(src, b), 0.0, levels_[top].defect.view(b));
+    level_v_step(top);
+    for (unsigned b = 0; b < slice_.n_blocks(); ++b) {
+      BlockVectorT<double> d = foreign_view(dst, b);
+      axpby(1.0, levels_[top].solution.view(b), 0.0, d);
+    }
+  }
+
+private:
+  struct Level {
+    Mesh mesh;
+    std::unique_ptr<StokesMatrixFreeOperator<dim, double>> K;
+    std::shared_ptr<StokesSpaces> spaces;
+    std::unique_ptr<SystemMatrixStokes<dim, double>> A;
+    std::unique_ptr<StokesSystem<dim, double>> system;
+    std::unique_ptr<PreconditionVankaStokes<double>> vanka;
+    std::unique_ptr<PreconditionRelaxationStokes<StokesSystem<dim, double>>> relax;
+    std::unique_ptr<MGTwoLevelTransfer<double>> tr_u, tr_p; // to the level below
+    double omega = 1.0;
+    mutable StokesBlockVector defect, solution, t, tmp;
+  };
+  BlockVectorT<double> foreign_view(const StokesBlockVector &x, unsigned b) const
+  {
+    const StokesSpaces &sp = *levels_.back().spaces;
+    BlockVectorT<double> v;
+    double *base = x.blocks()[b].data();
+    if (slice_.decompose(b)[1] == 0) {
+      const size_t nu = size_t(stfem_stokes_n_velocity_dofs(levels_.back().K->handle()));
+      void *ptrs[3] = {base, base + nu, base + 2 * nu};
+      v.wrap(sp.q2, ptrs, 3);
+    } else {
+      void *ptrs[1] = {base};
+      v.wrap(sp.q1, ptrs, 1);
+    }
+    return v;
+  }
+  // MGSmootherPrecondition::smooth / apply: u (= | +=) P (rhs - A u), `steps` times
+  void smooth(unsigned level, bool from_zero) const
+  {
+    const Level &L = levels_[level];
+    const unsigned steps = data_.smoothing_steps * (data_.variable ? 1u << (unsigned(levels_.size()) - 1 - level) : 1u);
+    unsigned i = 0;
+    if (from_zero) {
+      L.relax->vmult(L.solution, L.defect);
+      i = 1;
+    }
+    for (; i < steps; ++i) {
+      reinit_like(L.tmp, L.defect);
+      L.system->vmult(L.t, L.solution);
+      axpby(1.0, L.defect, -1.0, L.t);
+      L.relax->vmult(L.tmp, L.t);
+      axpby(1.0, L.tmp, 1.0, L.solution);
+    }
+  }
+  // Multigrid::level_v_step
+  void level_v_step(unsigned level) const
+  {
+    const Level &L = levels_[level];
+    if (level == 0) { // MGCoarseGridApplySmoother
+      smooth(0, true);
+      return;
+    }
+    const Level &C = levels_[level - 1];
+    smooth(level, true);
+    L.system->vmult(L.t, L.solution);
+    axpby(1.0, L.defect, -1.0, L.t);
+    set_zero(C.defect);
+    for (unsigned b = 0; b < slice_.n_blocks(); ++b) { // MGTwoLevelBlockTransfer::restrict_and_add: block by block with its variable's transfer
+      const MGTwoLevelTransfer<double> &tr = slice_.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
+      check(stfem_transfer_restrict(tr.handle(), C.defect.view(b).handle(), L.t.view(b).handle(), 1, nullptr), "GMGStokes: restrict_and_add");
+    }
+    level_v_step(level - 1);
+    for (unsigned b = 0; b < slice_.n_blocks(); ++b) {
+      const MGTwoLevelTransfer<double> &tr = slice_.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
+      check(stfem_transfer_prolongate(tr.handle(), L.solution.view(b).handle(), C.solution.view(b).handle(), 1, nullptr), "GMGStokes: prolongate_and_add");
+    }
+    smooth(level, false);
+  }
+  AdditionalData data_;
+  BlockSlice slice_;
+  FullMatrix<double> Alpha_, Beta_;
+  std::vector<Level> levels_;
+};
+
+// The relaxation parameter of PreconditionRelaxation when the reference leaves it at 0 (parameters.h:19, stmg.h:1207-1213): deal.II
+// estimates the largest eigenvalue of P^-1 A with a power iteration and takes 2 / (alpha + beta), beta = 1.2 lambda, alpha =
+// min(0.9 beta, 1) for smoothing_range <= 1 (see estimate_relaxation in stmg.h); the same for the two-variable system.
+template <typename System>
+double estimate_relaxation_stokes(const System &A, const PreconditionVankaStokes<double> &P, unsigned n_iterations, double smoothing_range)
+{
+  StokesBlockVector v, w, z;
+  A.initialize_dof_vector(v);
+  A.initialize_dof_vector(w);
+  A.initialize_dof_vector(z);
+  for (unsigned b = 0; b < v.n_blocks(); ++b) {
+    const size_t n = v.blocks()[b].size();
+    std::vector<double> guess(n);
+    double mean = 0.0;
+    for (size_t i = 0; i < n; ++i) mean += double(i % 11);
+    mean /= double(n);
+    for (size_t i = 0; i < n; ++i) guess[i] = double(i % 11) - mean;
+    v.blocks()[b].copy_from_host(guess);
+  }
+  axpby(0.0, v, 1.0 / norm(v), v);
+  double lambda = 0.0;
+  for (unsigned it = 0; it < n_iterations; ++it) {
+    A.vmult(z, v);
+    P.vmult(w.blocks(), z.blocks());
+    lambda = dot(v, w);
+    const double nw = norm(w);
+    if (!(nw > 0)) break;
+    axpby(1.0 / nw, w, 0.0, v);
+  }
+  lambda = std::abs(lambda);
+  if (!(lambda > 0) || !std::isfinite(lambda)) return 1.0;
+  const double beta = 1.2 * lambda, alpha = smoothing_range > 1.0 ? beta / smoothing_range : std::min(0.9 * beta, 1.0);
+  return 2.0 / (alpha + beta);
+}
 
 // A vector function of (x, t) at a list of points: out[c][i] = f_c(points[3 i .. 3 i + 2], t)
 using VectorPointFunction = std::function<void(double time, const std::vector<double> &points, std::array<std::vector<double>, 3> &out)>;

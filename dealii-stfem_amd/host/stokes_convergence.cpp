@@ -4,13 +4,17 @@
 // of the two-variable cell-patch Vanka smoother (the smoother of the reference's Stokes multigrid levels, tests/tp_03stokes.cc:714-726).
 // The reference's exact solution (include/exact_solution.h:199-325) is two-dimensional; this driver uses its 3D analogue: the
 // velocity is the curl of psi e_z, psi = sin t (sin pi x sin pi y sin pi z)^2, the pressure sin t cos pi x cos pi y cos pi z.
-// Usage: stokes_convergence <type 0 = cG | 1 = dG> <k> <refinement> [vanka sweeps = 3] [omega = 0.6] [viscosity = 1] [cells per direction]
-//                           [end_time = 1]
+// With mg=<levels> the preconditioner is one V-cycle of the geometric multigrid of the reference's Stokes runs (GMGStokes in
+// host/stfem/stokes_solver.h: <levels> space levels, relaxation sweeps of the Vanka smoother on every level, 2^(levels - 1 - l) smoothing
+// steps on level l); the errors do not depend on the preconditioner, the iteration counts do.
+// Usage: stokes_convergence <type 0 = cG | 1 = dG> <k> <refinement> [vanka sweeps = 3] [omega = 0: estimated] [viscosity = 1] [cells per direction]
+//                           [end_time = 1] [mg=<levels>]
 // Prints: cells u-dofs p-dofs t-dofs  u:Linf-Linf  u:L2-L2  u:L2-H1semi  p:L2-L2  gmres-iterations-per-solve
 #include "stfem/stokes_solver.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 using namespace stfem;
 
@@ -24,8 +28,16 @@ inline double dB(double s) { return PI * std::cos(2 * PI * s); }
 inline double d2B(double s) { return -4 * PI * PI * B(s); }
 } // namespace
 
-int main(int argc, char **argv)
+int main(int argc_all, char **argv_all)
 {
+  unsigned mg_levels = 0;
+  std::vector<char *> pos;
+  for (int i = 0; i < argc_all; ++i) {
+    if (i > 0 && std::strncmp(argv_all[i], "mg=", 3) == 0) mg_levels = unsigned(std::atoi(argv_all[i] + 3));
+    else pos.push_back(argv_all[i]);
+  }
+  const int argc = int(pos.size());
+  char **argv = pos.data();
   if (argc < 4) {
     std::fprintf(stderr, "usage: %s type k refinement [sweeps] [omega] [viscosity] [cells] [end_time]\n", argv[0]);
     return 2;
@@ -33,7 +45,7 @@ int main(int argc, char **argv)
   const auto type = std::atoi(argv[1]) == 0 ? TimeStepType::CGP : TimeStepType::DG;
   const unsigned k = std::atoi(argv[2]), refinement = std::atoi(argv[3]);
   const unsigned sweeps = argc > 4 ? std::atoi(argv[4]) : 3;
-  const double omega = argc > 5 ? std::atof(argv[5]) : 0.6;
+  const double omega_arg = argc > 5 ? std::atof(argv[5]) : 0.0; // 0: estimated (deal.II's PreconditionRelaxation with relaxation = 0)
   const double nu = argc > 6 ? std::atof(argv[6]) : 1.0;
   const int n = argc > 7 ? std::atoi(argv[7]) : 1 << refinement;
   const double tau = std::ldexp(1.0, -int(refinement + 1)), end_time = argc > 8 ? std::atof(argv[8]) : 1.0;
@@ -54,6 +66,7 @@ int main(int argc, char **argv)
     SystemMatrixStokes<3, double> rhs_matrix(K, cgp ? w[2] : zero, cgp ? w[3] : w[2], slice);
     StokesSystem<3, double> system(matrix, spaces, K.handle(), slice);
     PreconditionVankaStokes<double> vanka(K, w[0], w[1], slice);
+    const double omega = omega_arg != 0.0 ? omega_arg : estimate_relaxation_stokes(system, vanka);
     PreconditionRelaxationStokes<StokesSystem<3, double>> preconditioner(system, vanka, omega, sweeps);
 
     const VectorPointFunction force = [&](double t, const std::vector<double> &p, std::array<std::vector<double>, 3> &out) {
@@ -97,8 +110,26 @@ int main(int argc, char **argv)
     };
     const PointFunction no_gradient = [](double, const std::vector<double> &p, std::vector<double> &out) { out.assign(p.size(), 0.0); };
 
-    TimeIntegratorStokes<3, StokesSystem<3, double>, decltype(preconditioner)> step(type, k, Alpha_1, Gamma_1, 1e-12, system, preconditioner,
-                                                                                    rhs_matrix, force, true);
+    // the preconditioner behind one interface: relaxation sweeps on the finest level, or one V-cycle
+    std::unique_ptr<GMGStokes<3>> gmg;
+    if (mg_levels > 0) {
+      GMGStokes<3>::AdditionalData ad;
+      ad.smoothing_degree = sweeps;
+      ad.relaxation = omega_arg;
+      gmg = std::make_unique<GMGStokes<3>>(mesh, mg_levels, nu, w[0], w[1], slice, ad);
+      for (unsigned l = 0; l < gmg->n_levels(); ++l) std::fprintf(stderr, "level %u: relaxation %.4f\n", l, gmg->relaxation(l));
+    } else
+      std::fprintf(stderr, "relaxation %.4f\n", omega);
+    struct Prec {
+      const PreconditionRelaxationStokes<StokesSystem<3, double>> *relax;
+      const GMGStokes<3> *gmg;
+      void vmult(StokesBlockVector &dst, const StokesBlockVector &src) const
+      {
+        if (gmg) gmg->vmult(dst, src);
+        else relax->vmult(dst, src);
+      }
+    } prec{&preconditioner, gmg.get()};
+    TimeIntegratorStokes<3, StokesSystem<3, double>, Prec> step(type, k, Alpha_1, Gamma_1, 1e-12, system, prec, rhs_matrix, force, true);
     // ErrorCalculator (exact_solution.h:503-649): QGauss(k + 1) in time; QGauss(3) per direction for the velocity components, QGauss(2) for the pressure
     std::vector<ErrorCalculator<double>> err_u;
     for (int c = 0; c < 3; ++c) err_u.emplace_back(type, k, 3, spaces->q2, exact_u(c), exact_grad_u(c));
