@@ -408,7 +408,8 @@ int stfem_stokes_mass_vmult(stfem_stokes_ctx *ctx, double *dst_u, const double *
  * entries with |.| <= 10 eps are skipped as in internal::scatter (operators.h:91-110); dst is
  * zeroed first.  Up to four time dofs: one set of colour launches for the whole system (every cell is evaluated for all sources, the
  * weighted results are summed in registers, every destination is written once); more: one fused launch per source time dof.  The reference's Tvmult for this class
- * (operators.h:702-745) indexes dst by the source time dof and is not a transpose; it is not built. */
+ * (operators.h:702-745) indexes dst by the source time dof and is not a transpose: it is this entry with the effective matrices of
+ * that rule (SystemMatrixStokes::Tvmult in host/stfem/stokes.h builds them). */
 int stfem_stokes_st_vmult(stfem_stokes_ctx *ctx, int n_timesteps_at_once, int n_timedofs,
                           int variable_major, const double *Alpha, const double *Beta,
                           double *const *dst_blocks, const double *const *src_blocks, void *stream);
