@@ -97,6 +97,58 @@ def measured_traffic(kernel_name, general):
         return None, None
 
 
+def bench_stokes(args, stfem, torch, dev):
+    """BASELINE configs[4] on one GPU: SystemMatrixStokes::vmult (operators.h:825-867), FE_Q(2)^3 x FE_Q(1) x cG(time_degree), unit cube,
+    homogeneous Dirichlet velocity.  A step = one space-time vmult; inputs resident in HBM; HIP events on the launch stream."""
+    n = 64 if args.cells == 72 else args.cells  # (72 is the default of the heat line)
+    r = 1 if args.time_degree == 2 else args.time_degree
+    op = stfem.StokesMatrixFreeOperator((n, n, n), viscosity=1.0, device=dev.index or 0)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 64, 1)
+    nt = r
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    sizes = {0: 3 * op.n_velocity, 1: op.n_pressure}
+    keep, src, dst = [], [None] * (2 * nt), [None] * (2 * nt)
+    for d in range(nt):
+        for v in range(2):
+            j = stfem.stokes_block_index(nt, 0, v, d)
+            a = torch.rand(sizes[v], dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+            b = torch.zeros(sizes[v], dtype=torch.float64, device=dev)
+            keep += [a, b]
+            src[j], dst[j] = a.data_ptr(), b.data_ptr()
+    for _ in range(args.warmup):
+        op.st_vmult(Alpha, Beta, 1, nt, dst, src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        op.st_vmult(Alpha, Beta, 1, nt, dst, src)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = e0.elapsed_time(e1) / args.steps
+    dofs = nt * (3 * op.n_velocity + op.n_pressure)
+    alg_bytes = 16.0 * dofs
+    achieved = alg_bytes / (kms * 1e-3) / 1e9
+    out = {
+        "metric": "space-time DoF/s per vmult (Stokes block operator, Q2/Q1 x cG(%d)); achieved HBM GB/s" % r,
+        "value": dofs * args.steps / elapsed, "unit": "space-time DoF/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"Stokes space-time block operator, FE_Q(2)^3 x FE_Q(1) x cG({r}), {n}x{n}x{n} cells, {dofs} space-time DoFs "
+                               "= BASELINE configs[4] on one GPU",
+                   "n_blocks": 2 * nt, "cells_per_gpu": n ** 3,
+                   "kernel": "st_sweep_pencil (velocity components) + stokes_div_kernel beside it + stokes_grad_kernel"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_source": "profiles/r3/stokes (counter passes of tools/stokes_bench.py, per kernel)",
+                     "kernel_ms": kms, "algorithmic_bytes_per_launch": alg_bytes},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+    del keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,9 +178,10 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="N > 1: compare every rank's slab of the sharded vmult with a single-domain vmult of the "
                          "whole mesh computed on the same GPU (small meshes only)")
-    ap.add_argument("--config", type=int, default=1, choices=[1, 3],
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
                     help="1: BASELINE configs[1] / [2] (heat, the contract line); 3: configs[3] = wave equation, Q3 x dG(2), "
-                         "80^3 cells on [-1,1]^3 per GPU, Coefficient(1,9,16) per cell (extra line, not the contract metric's workload)")
+                         "80^3 cells on [-1,1]^3 per GPU, Coefficient(1,9,16) per cell; 4: configs[4] = Stokes block operator, Q2/Q1 x cG(1), "
+                         "64^3 cells (--cells) on one GPU (extra lines, not the contract metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-gpu-point", action="store_true",
                     help="N > 1, strong scaling: do not run the whole mesh on rank 0's GPU after the timed region")
@@ -160,6 +213,10 @@ def main():
     stfem.lib()
     from importlib import import_module
     dmod = import_module("dealii-stfem_amd.distributed")
+    if args.config == 4:
+        if world != 1:
+            raise SystemExit("--config 4 is a one-GPU line (the Stokes operator has no partitioned form yet)")
+        return bench_stokes(args, stfem, torch, dev)
 
     if args.distort is None:
         args.distort = 0.0 if world == 1 else 0.15

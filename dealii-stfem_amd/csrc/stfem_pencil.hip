@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void st_pencil_fixup(const SweepParams prm, co
   // mesh's last column
   const int x_begin = P, x_end = P * nslot + (last_x ? 1 : 0);
   const int Yn = P * ncy_t + (last_y ? 1 : 0), Zn = P * nlay + (last_z ? 1 : 0);
-  const int lpr = pp.tX <= 32 ? 32 : 64, nrg = 256 / lpr;
+  const int lpr = pp.tX <= 16 ? 16 : (pp.tX <= 32 ? 32 : 64), nrg = 256 / lpr; // lanes per row: narrow tiles (Q3 x 3 blocks: 13 columns) keep more rows per workgroup
   const int X = threadIdx.x % lpr, rg = threadIdx.x / lpr;
   if (X < x_begin || X >= x_end) return;
   const int64_t plane_stride = int64_t(prm.nx) * prm.ny;

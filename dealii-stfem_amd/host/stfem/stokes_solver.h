@@ -23,6 +23,18 @@ struct StokesSpaces {
     MatrixFreeOperator<3, 1, double> b(m1, 1, 1.0, 0.0);
     q1 = b.context();
   }
+  // z-slab partition (the mesh is this rank's slab, interface faces taken out of its Dirichlet mask): the operator leaves partial
+  // sums in the interface planes of every velocity component and of the pressure (tests/test_gpu_stokes.py::
+  // test_stokes_on_z_slabs_equals_whole_mesh); StokesSystem::vmult completes them with the scalar spaces' add-exchange
+  // (stfem_halo_begin / end), inner products count owned planes only (stfem_dot_global) - as for the scalar operators
+  void set_partition(const std::shared_ptr<Communicator> &comm, int lower_rank, int upper_rank)
+  {
+    for (auto &c : {q2, q1}) {
+      c->comm = comm;
+      c->lower_rank = lower_rank;
+      c->upper_rank = upper_rank;
+    }
+  }
 };
 
 // BlockVectorT over a two-variable BlockSlice (LinearAlgebra::distributed::BlockVector with velocity and pressure blocks)
@@ -104,7 +116,12 @@ public:
     : A(A), spaces(spaces), stokes(stokes), slice(slice)
   {}
   void initialize_dof_vector(StokesBlockVector &v) const { v.reinit(spaces, stokes, slice); }
-  void vmult(StokesBlockVector &dst, const StokesBlockVector &src, void *stream = nullptr) const { A.vmult(dst.blocks(), src.blocks(), stream); }
+  void vmult(StokesBlockVector &dst, const StokesBlockVector &src, void *stream = nullptr) const
+  {
+    A.vmult(dst.blocks(), src.blocks(), stream);
+    if (spaces->q2->comm) // partitioned: dst.compress(add) on every block through its scalar view
+      for (unsigned b = 0; b < dst.n_blocks(); ++b) compress_add(*dst.view(b).context(), dst.view(b).handle(), stream);
+  }
 
 private:
   const SystemMatrixStokes<dim, Number> &A;

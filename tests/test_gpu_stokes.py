@@ -328,3 +328,64 @@ def test_stokes_dg_pressure_vs_oracle(nc, distort, mask, weak, stfem):
         op.st_vmult(Alpha, Beta, ns, nt, dst, src, True)
         for j in range(nb):
             assert rel(dst[j].download(), ref[j]) < TOL, (ns, r, j)
+
+
+@pytest.mark.parametrize("world,dg", [(2, False), (3, False), (2, True)])
+def test_stokes_on_z_slabs_equals_whole_mesh(world, dg, stfem):
+    """The Stokes operator shards like the scalar one (BASELINE configs[4] is an 8-GPU configuration): on a z-slab whose interface
+    faces are taken out of the Dirichlet mask the kernels leave PARTIAL sums in the interface planes of the velocity components and of
+    the FE_Q(1) pressure (the gather-form coupling kernels count the slab's own cells only; FE_DGP pressure DoFs are cell-local); adding
+    the two sides' planes - the add-exchange stfem_halo_begin / end performs on the scalar views of the blocks - gives the whole-mesh
+    result.  Here the exchange is done on the host."""
+    nc, nu_ = (3, 2, 6), 0.8
+    weak = [0]  # a weak (Nitsche) x- face: boundary cells of every slab
+    mask = 63 & ~1
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, 2, 0.1, 1)
+    nt = 2
+    rng = np.random.default_rng(8)
+    ndu = [2 * c + 1 for c in nc]
+    ndp = [c + 1 for c in nc]
+    whole = stfem.StokesMatrixFreeOperator(nc, dirichlet_mask=mask, viscosity=nu_, weak_boundary_ids=weak, dg_pressure=dg)
+    var = [0] * nt + [1] * nt
+    X = [rng.uniform(-1, 1, 3 * whole.n_velocity if v == 0 else whole.n_pressure) for v in var]
+    src = [whole.initialize_dof_vector(v, x) for v, x in zip(var, X)]
+    dst = [whole.initialize_dof_vector(v) for v in var]
+    whole.st_vmult(Alpha, Beta, 1, nt, dst, src)
+    want = [d.download() for d in dst]
+    bounds = [round(nc[2] * r / world) for r in range(world + 1)]
+    parts = []
+    for r in range(world):
+        z0, z1 = bounds[r], bounds[r + 1]
+        m = mask
+        if r > 0:
+            m &= ~16
+        if r < world - 1:
+            m &= ~32
+        snc = (nc[0], nc[1], z1 - z0)
+        op = stfem.StokesMatrixFreeOperator(snc, lower=(0, 0, z0 / nc[2]), upper=(1, 1, z1 / nc[2]), dirichlet_mask=m, viscosity=nu_,
+                                            weak_boundary_ids=weak, dg_pressure=dg)
+        pu, pp = ndu[0] * ndu[1], ndp[0] * ndp[1]
+
+        def cut(b, x):
+            if var[b] == 0:
+                return x.reshape(3, ndu[2], pu)[:, 2 * z0:2 * z1 + 1].reshape(-1)
+            if dg:
+                return x.reshape(nc[2], -1)[z0:z1].reshape(-1)
+            return x.reshape(ndp[2], pp)[z0:z1 + 1].reshape(-1)
+
+        s = [op.initialize_dof_vector(v, cut(b, X[b])) for b, v in enumerate(var)]
+        d = [op.initialize_dof_vector(v) for v in var]
+        op.st_vmult(Alpha, Beta, 1, nt, d, s)
+        parts.append((z0, z1, [q.download() for q in d], cut))
+    # the add-exchange: every interface plane is the sum of the two sides' partial sums
+    for b, v in enumerate(var):
+        if v == 1 and dg:
+            got = np.concatenate([p[2][b] for p in parts])
+            assert rel(got, want[b]) < TOL
+            continue
+        nz, plane, comps = (ndu[2], ndu[0] * ndu[1], 3) if v == 0 else (ndp[2], ndp[0] * ndp[1], 1)
+        step = 2 if v == 0 else 1
+        total = np.zeros((comps, nz, plane))
+        for z0, z1, out, _ in parts:
+            total[:, step * z0:step * z1 + 1] += out[b].reshape(comps, step * (z1 - z0) + 1, plane)
+        assert rel(total.reshape(-1), want[b]) < TOL, b
