@@ -99,14 +99,44 @@ inline double dot(const StokesBlockVector &a, const StokesBlockVector &b)
   return s;
 }
 inline double norm(const StokesBlockVector &x) { return std::sqrt(dot(x, x)); }
-// the Gram-Schmidt step of the Krylov solver (modified scheme: one inner product and one update per basis vector)
+// the Gram-Schmidt step of the Krylov solver: classical scheme, the k inner products of a pass in one launch per block
+// (stfem_multi_dot on the block's scalar view, summed over the blocks on the host), the k updates in one launch per block
+// (stfem_multi_axpy); a second pass when the first cancelled most of w, as for the scalar systems (time_integrators.h)
 inline double orthogonalize(const std::vector<StokesBlockVector> &vs, unsigned k, StokesBlockVector &w, double *h)
 {
-  for (unsigned i = 0; i < k; ++i) {
-    h[i] = dot(w, vs[i]);
-    axpby(-h[i], vs[i], 1.0, w);
+  const unsigned nb = w.n_blocks();
+  std::vector<const stfem_vec *> handles(k);
+  std::vector<double> part(k), minus(k);
+  auto pass = [&](double *hh) {
+    for (unsigned i = 0; i < k; ++i) hh[i] = 0.0;
+    for (unsigned b = 0; b < nb; ++b) {
+      for (unsigned i = 0; i < k; ++i) handles[i] = vs[i].view(b).handle();
+      check(stfem_multi_dot(w.view(b).context()->h, int(k), handles.data(), w.view(b).handle(), 0, part.data(), nullptr), "stfem_multi_dot");
+      for (unsigned i = 0; i < k; ++i) hh[i] += part[i];
+    }
+    for (unsigned i = 0; i < k; ++i) minus[i] = -hh[i];
+    for (unsigned b = 0; b < nb; ++b) {
+      for (unsigned i = 0; i < k; ++i) handles[i] = vs[i].view(b).handle();
+      check(stfem_multi_axpy(w.view(b).context()->h, int(k), minus.data(), handles.data(), w.view(b).handle(), nullptr), "stfem_multi_axpy");
+    }
+  };
+  if (k == 0 || k > 240 || w.spaces()->q2->comm) { // (partitioned vectors: the modified scheme with reducing inner products)
+    for (unsigned i = 0; i < k; ++i) {
+      h[i] = dot(w, vs[i]);
+      axpby(-h[i], vs[i], 1.0, w);
+    }
+    return norm(w);
   }
-  return norm(w);
+  const double before = dot(w, w);
+  pass(h);
+  double after = dot(w, w);
+  if (!(after > 0.01 * before)) {
+    std::vector<double> h2(k);
+    pass(h2.data());
+    for (unsigned i = 0; i < k; ++i) h[i] += h2[i];
+    after = dot(w, w);
+  }
+  return std::sqrt(std::max(after, 0.0));
 }
 
 // SystemMatrixStokes on StokesBlockVector (the operator interface the solver consumes)

@@ -12,6 +12,7 @@
 // Prints: cells u-dofs p-dofs t-dofs  u:Linf-Linf  u:L2-L2  u:L2-H1semi  p:L2-L2  gmres-iterations-per-solve
 #include "stfem/stokes_solver.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,8 +143,12 @@ int main(int argc_all, char **argv_all)
     const size_t nu_dofs = size_t(stfem_stokes_n_velocity_dofs(K.handle()));
     double time = 0.0, l2 = 0.0, l8 = -1.0, h1 = 0.0, l2p = 0.0;
     unsigned solves = 0, iterations = 0;
+    double solve_seconds = 0.0;
     while (time < end_time - 1e-12) {
+      const auto t0 = std::chrono::steady_clock::now();
       step.solve(x, prev, rhs, time, tau);
+      (void)dot(x, x); // synchronises
+      solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       iterations += step.last_step();
       ++solves;
       // component c of the time dofs as a block vector of the scalar velocity space; the pressure blocks likewise
@@ -172,6 +177,8 @@ int main(int argc_all, char **argv_all)
       axpby(1.0, x.view(slice.index(0, 1, nt - 1)), 0.0, prev.view(1));
       time += tau;
     }
+    std::fprintf(stderr, "%u slab solves (right-hand side + FGMRES): %.3f s for %u iterations = %.2f ms per iteration\n", solves, solve_seconds, iterations,
+                 1e3 * solve_seconds / std::max(1u, iterations));
     std::printf("%d %lld %lld %u %.12e %.12e %.12e %.12e %.2f\n", n * n * n, 3ll * (long long)nu_dofs, (long long)stfem_stokes_n_pressure_dofs(K.handle()), nt, l8,
                 std::sqrt(l2), std::sqrt(h1), std::sqrt(l2p), double(iterations) / solves);
     return 0;
