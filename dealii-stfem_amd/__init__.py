@@ -97,6 +97,8 @@ SIGNATURES = {
     "stfem_ghost_update": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "stfem_halo_begin": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "stfem_halo_end": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "stfem_halo_begin_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "stfem_planes_move": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "stfem_dot_global": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _dp, _vp]),
     "stfem_support_points": (C.c_int, [_vp, _dp]),
     "stfem_quadrature_points": (C.c_int, [_vp, C.c_int, _dp]),

@@ -1239,6 +1239,50 @@ int stfem_plane_unpack(stfem_ctx *c, stfem_vec *v, int iz, const void *buf, int 
   return STFEM_OK;
 }
 
+extern "C++" {
+struct PlanesMoveArgs {
+  const void *src[MAX_BLOCKS];
+  void *dst[MAX_BLOCKS];
+};
+// blockIdx.y = plane, blockIdx.z = block; the first / last plane of the range may be added to the destination instead of copied
+template <typename T>
+__global__ __launch_bounds__(256) void planes_move_kernel(int64_t plane, int nplanes, int add_mask, const PlanesMoveArgs a)
+{
+  const int q = blockIdx.y;
+  const bool add = (q == 0 && (add_mask & 1)) || (q == nplanes - 1 && (add_mask & 2));
+  const T *s = static_cast<const T *>(a.src[blockIdx.z]) + plane * q;
+  T *d = static_cast<T *>(a.dst[blockIdx.z]) + plane * q;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += int64_t(gridDim.x) * blockDim.x) d[i] = add ? d[i] + s[i] : s[i];
+}
+} // extern "C++"
+
+// nplanes consecutive DoF planes of src (from plane iz_src, context cs) to dst (from plane iz_dst, context cd: the same plane size and
+// Number); add_mask bit 0: the first plane is ADDED to the destination's, bit 1: the last one.  One launch for all blocks.
+int stfem_planes_move(stfem_ctx *cs, const stfem_vec *src, int iz_src, stfem_ctx *cd, stfem_vec *dst, int iz_dst, int nplanes, int add_mask,
+                      void *stream)
+{
+  if (!cs || !cd || !src || !dst || src->ctx != cs || dst->ctx != cd || nplanes < 1 || iz_src < 0 || iz_dst < 0 || iz_src + nplanes > cs->nd[2] ||
+      iz_dst + nplanes > cd->nd[2])
+    return STFEM_ERR_INVALID_ARGUMENT;
+  if (cs->nd[0] != cd->nd[0] || cs->nd[1] != cd->nd[1] || cs->prec != cd->prec || cs->device != cd->device || src->nb != dst->nb)
+    return STFEM_ERR_SHAPE_MISMATCH;
+  if (src->nb > MAX_BLOCKS) return STFEM_ERR_UNSUPPORTED;
+  HIP_TRY(hipSetDevice(cd->device));
+  const int64_t plane = int64_t(cd->nd[0]) * cd->nd[1];
+  PlanesMoveArgs a;
+  std::memset(&a, 0, sizeof(a));
+  for (int b = 0; b < src->nb; ++b) {
+    a.src[b] = static_cast<const char *>(src->blk[b]) + size_t(plane) * iz_src * cs->es;
+    a.dst[b] = static_cast<char *>(dst->blk[b]) + size_t(plane) * iz_dst * cd->es;
+  }
+  const dim3 grid((unsigned)std::min<int64_t>((plane + 255) / 256, 1024), nplanes, src->nb);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cd->prec) hipLaunchKernelGGL(planes_move_kernel<float>, grid, dim3(256), 0, st, plane, nplanes, add_mask, a);
+  else hipLaunchKernelGGL(planes_move_kernel<double>, grid, dim3(256), 0, st, plane, nplanes, add_mask, a);
+  if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "planes_move_kernel");
+  return STFEM_OK;
+}
+
 // ------------------------------------------------------------------------------------ host helpers
 
 // time-multigrid transfer matrices (fe_time.h:749-898); out may be NULL to ask for the dimensions only

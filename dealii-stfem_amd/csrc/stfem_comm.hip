@@ -227,12 +227,24 @@ static int check_neighbours(const stfem_comm *c, int lower, int upper)
 
 int stfem_halo_begin(stfem_ctx *ctx, stfem_comm *c, stfem_vec *v, int lower, int upper, void *stream)
 {
-  if (!ctx || !c || !v || check_neighbours(c, lower, upper) != STFEM_OK || c->pending)
+  return stfem_halo_begin_split(c, ctx, v, ctx, v, lower, upper, stream);
+}
+
+// The same with the two interface planes taken from two vectors: plane 0 of v_lo (context ctx_lo) goes to the lower neighbour, the
+// top plane of v_hi (context ctx_hi) to the upper one.  A rank that sweeps its interface cell layers first (into vectors of their
+// own) starts the exchange with this before it sweeps its interior cells; stfem_halo_end then adds what arrived into the assembled
+// destination vector as usual.
+int stfem_halo_begin_split(stfem_comm *c, stfem_ctx *ctx_lo, stfem_vec *v_lo, stfem_ctx *ctx_hi, stfem_vec *v_hi, int lower, int upper, void *stream)
+{
+  if (!ctx_lo || !ctx_hi || !c || !v_lo || !v_hi || check_neighbours(c, lower, upper) != STFEM_OK || c->pending)
     return STFEM_ERR_INVALID_ARGUMENT;
-  size_t pb;
-  int nz;
-  int rc = plane_geometry(ctx, v, pb, nz);
+  size_t pb, pb_hi;
+  int nz_lo, nz;
+  int rc = plane_geometry(ctx_lo, v_lo, pb, nz_lo);
+  if (rc == STFEM_OK) rc = plane_geometry(ctx_hi, v_hi, pb_hi, nz);
   if (rc != STFEM_OK) return rc;
+  if (pb != pb_hi || stfem_ctx_precision(ctx_lo) != stfem_ctx_precision(ctx_hi)) return STFEM_ERR_SHAPE_MISMATCH;
+  stfem_ctx *ctx = ctx_hi;
   if (lower < 0 && upper < 0) {
     c->lower = lower; c->upper = upper; c->plane_bytes = pb;
     c->pending = true;
@@ -243,8 +255,8 @@ int stfem_halo_begin(stfem_ctx *ctx, stfem_comm *c, stfem_vec *v, int lower, int
   char *ts = static_cast<char *>(c->buf), *bs = ts + pb, *tr = bs + pb, *br = tr + pb;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // this rank's partial sums of its two interface planes
-  if (upper >= 0 && (rc = stfem_plane_pack(ctx, v, nz - 1, ts, st)) != STFEM_OK) return rc;
-  if (lower >= 0 && (rc = stfem_plane_pack(ctx, v, 0, bs, st)) != STFEM_OK) return rc;
+  if (upper >= 0 && (rc = stfem_plane_pack(ctx_hi, v_hi, nz - 1, ts, st)) != STFEM_OK) return rc;
+  if (lower >= 0 && (rc = stfem_plane_pack(ctx_lo, v_lo, 0, bs, st)) != STFEM_OK) return rc;
   COMM_HIP(hipEventRecord(c->packed, st));
   COMM_HIP(hipStreamWaitEvent(c->stream, c->packed, 0));
   const ncclDataType_t dt = stfem_ctx_precision(ctx) ? ncclFloat : ncclDouble;

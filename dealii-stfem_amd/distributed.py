@@ -152,6 +152,9 @@ class Communicator:
     def halo_begin(self, ctx, vec, lower, upper, stream=None):
         self._chk(self._L.stfem_halo_begin(ctx._h, self._h, vec._h, lower, upper, stream), "stfem_halo_begin")
 
+    def halo_begin_split(self, ctx_lo, v_lo, ctx_hi, v_hi, lower, upper, stream=None):
+        self._chk(self._L.stfem_halo_begin_split(self._h, ctx_lo._h, v_lo._h, ctx_hi._h, v_hi._h, lower, upper, stream), "stfem_halo_begin_split")
+
     def halo_end(self, ctx, vec, stream=None):
         self._chk(self._L.stfem_halo_end(ctx._h, self._h, vec._h, stream), "stfem_halo_end")
 
@@ -175,3 +178,50 @@ def sharded_vmult_abi(slab, comm, ctx, local_vmult, dst, stream=None):
     lo, up = neighbours(slab)
     comm.halo_begin(ctx, dst, lo, up, stream)
     comm.halo_end(ctx, dst, stream)
+
+
+class OverlappedSlabOperator:
+    """The space-time vmult of one z-slab with the interface-plane exchange hidden behind the interior cells (deal.II's cell_loop
+    overlaps the ghost exchange with the cells that do not need it, include/operators.h:1016-1017): the bottom and the top CELL LAYER of
+    the slab are swept first, each on a one-layer context into a small vector of its own; their outer planes - the slab's two interface
+    planes, complete - start travelling (stfem_halo_begin_split, RCCL on the communicator's stream); the interior layers are swept
+    meanwhile straight into the destination vector; the two thin results are moved in (stfem_planes_move: the plane each shares with
+    the interior is added); stfem_halo_end adds what arrived.  Needs at least three cell layers.
+
+    make_ctx(z0, z1, dirichlet_mask) -> MatrixFreeOperator of the slab's local cell layers [z0, z1) (same x / y extent, degree and
+    Number as `ctx`, the context of the whole slab that `src` / `dst` belong to); make_system(ctx) -> the SystemMatrix on it."""
+
+    def __init__(self, stfem, ctx, make_ctx, make_system, src, dst, slab_mask):
+        self.stfem, self.ctx, self.src, self.dst = stfem, ctx, src, dst
+        nz = ctx.ncell[2]
+        if nz < 3:
+            raise ValueError("OverlappedSlabOperator: at least three cell layers per slab")
+        p = ctx.degree
+        self.p, self.nz = p, nz
+        plane_bytes = (p * ctx.ncell[0] + 1) * (p * ctx.ncell[1] + 1) * (8 if ctx.number == "double" else 4)
+        nb_in, nb_out = src.n_blocks, dst.n_blocks
+        lo_open, hi_open = slab_mask & ~32, slab_mask & ~16  # the bottom layer's upper face / the top layer's lower face are interior
+        self.bot = make_ctx(0, 1, lo_open)
+        self.top = make_ctx(nz - 1, nz, hi_open)
+        self.mid = make_ctx(1, nz - 1, slab_mask & ~48)
+        self.A_bot, self.A_top, self.A_mid = make_system(self.bot), make_system(self.top), make_system(self.mid)
+        view = lambda vec, c, z0, n: stfem.BlockVector(c, device_ptrs=[vec.block_ptr(b) + plane_bytes * p * z0 for b in range(n)])  # noqa: E731
+        self.src_bot, self.src_top, self.src_mid = view(src, self.bot, 0, nb_in), view(src, self.top, nz - 1, nb_in), view(src, self.mid, 1, nb_in)
+        self.dst_mid = view(dst, self.mid, 1, nb_out)
+        self.dst_bot, self.dst_top = stfem.BlockVector(self.bot, nb_out), stfem.BlockVector(self.top, nb_out)
+
+    def vmult(self, comm=None, lower=-1, upper=-1, stream=None, transpose=False):
+        L = self.stfem.lib()
+        p, nz = self.p, self.nz
+        ap = (lambda A, d, s_: A.Tvmult(d, s_, stream)) if transpose else (lambda A, d, s_: A.vmult(d, s_, stream))
+        ap(self.A_bot, self.dst_bot, self.src_bot)
+        ap(self.A_top, self.dst_top, self.src_top)
+        if comm is not None:
+            comm.halo_begin_split(self.bot, self.dst_bot, self.top, self.dst_top, lower, upper, stream)
+        ap(self.A_mid, self.dst_mid, self.src_mid)
+        rc = L.stfem_planes_move(self.bot._h, self.dst_bot._h, 0, self.ctx._h, self.dst._h, 0, p + 1, 2, stream)
+        assert rc == 0, rc
+        rc = L.stfem_planes_move(self.top._h, self.dst_top._h, 0, self.ctx._h, self.dst._h, p * (nz - 1), p + 1, 1, stream)
+        assert rc == 0, rc
+        if comm is not None:
+            comm.halo_end(self.ctx, self.dst, stream)

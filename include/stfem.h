@@ -206,6 +206,16 @@ int stfem_ghost_update(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, int lower
 int stfem_halo_begin(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, int lower_rank, int upper_rank,
                      void *stream);
 int stfem_halo_end(stfem_ctx *ctx, stfem_comm *comm, stfem_vec *v, void *stream);
+/* The exchange with the two interface planes taken from two vectors (plane 0 of v_lo goes down, the top plane of v_hi goes up): for
+ * a rank that sweeps its interface cell layers first, into vectors of their own, and its interior cells while the planes travel -
+ * deal.II's cell_loop overlaps the ghost exchange with the cells that do not need it (include/operators.h:1016-1017).
+ * stfem_halo_end on the assembled destination vector completes it.  stfem_planes_move copies nplanes consecutive DoF planes between
+ * vectors of two contexts with the same plane size (add_mask bit 0 / 1: the first / last plane is added instead): how the interface
+ * layers' results reach the destination vector (dealii-stfem_amd/distributed.py: OverlappedSlabOperator). */
+int stfem_halo_begin_split(stfem_comm *comm, stfem_ctx *ctx_lo, stfem_vec *v_lo, stfem_ctx *ctx_hi, stfem_vec *v_hi, int lower, int upper,
+                           void *stream);
+int stfem_planes_move(stfem_ctx *ctx_src, const stfem_vec *src, int iz_src, stfem_ctx *ctx_dst, stfem_vec *dst, int iz_dst, int nplanes,
+                      int add_mask, void *stream);
 /* stfem_dot followed by the sum over all ranks (synchronous) */
 int stfem_dot_global(stfem_ctx *ctx, stfem_comm *comm, const stfem_vec *a, const stfem_vec *b,
                      int64_t n_own, double *out, void *stream);

@@ -99,3 +99,39 @@ def test_cpp_caller_runs_partitioned(number, tmp_path, oracle_mod):
     n_own = n - plane
     want = float(np.sum(X1[:, :n_own] * Y[:, :n_own]))
     assert abs(xy - want) <= 10 * tol * abs(want)
+
+
+@pytest.mark.parametrize("distort", [0.0, 0.1])
+def test_overlapped_exchange_on_the_self_loop(distort):
+    """OverlappedSlabOperator with the RCCL exchange in the middle (stfem_halo_begin_split on the one-layer vectors before the interior
+    sweep, stfem_halo_end on the assembled vector after it), on the self-loop communicator: the same vector as sweep, then
+    stfem_halo_begin / end."""
+    stfem = importlib.import_module("dealii-stfem_amd")
+    dmod = importlib.import_module("dealii-stfem_amd.distributed")
+    p, nc = 3, (4, 3, 5)
+    mask = 63 & ~48
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    verts = stfem.mesh_vertices(nc, distort=distort, seed=3) if distort else None
+
+    def make_ctx(z0, z1, m):
+        snc = (nc[0], nc[1], z1 - z0)
+        if verts is not None:
+            v = np.asarray(verts).reshape(nc[2] + 1, -1)[z0:z1 + 1].reshape(-1)
+            return stfem.MatrixFreeOperator(p, snc, vertices=v, dirichlet_mask=m)
+        return stfem.MatrixFreeOperator(p, snc, lower=(0, 0, z0 / nc[2]), upper=(1, 1, z1 / nc[2]), dirichlet_mask=m)
+
+    ctx = make_ctx(0, nc[2], mask)
+    comm = dmod.Communicator(0, 1, 0, lambda raw: raw)
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    rng = np.random.default_rng(12)
+    src = stfem.BlockVector(ctx, nb).upload(rng.uniform(-1, 1, (nb, ctx.n_dofs)))
+    ref, dst = stfem.BlockVector(ctx, nb), stfem.BlockVector(ctx, nb)
+    A.vmult(ref, src)
+    comm.halo_begin(ctx, ref, 0, 0)
+    comm.halo_end(ctx, ref)
+    op = dmod.OverlappedSlabOperator(stfem, ctx, make_ctx, lambda c: stfem.SystemMatrix(c, Alpha, Beta), src, dst, mask)
+    for _ in range(2):  # (twice: the buffers and events of the communicator are reused)
+        op.vmult(comm, 0, 0)
+        want, got = ref.download(), dst.download()
+        assert np.linalg.norm(got - want) <= 1e-14 * np.linalg.norm(want)

@@ -431,3 +431,38 @@ def test_v_cycle_on_slabs_equals_whole_mesh(stfem, gnc, degrees, world, distort)
     parts.v_cycle(top, up, dp, 0.7)
     for R, v in zip(parts.levels[top], up):
         assert rel(v.download(), U[:, R["lo"]:R["hi"]]) < 1e-10
+
+
+@pytest.mark.parametrize("p,nc,number,distort", [(2, (4, 3, 5), "double", 0.0), (4, (6, 2, 4), "double", 0.0), (3, (3, 3, 6), "double", 0.12),
+                                                 (2, (5, 4, 3), "float", 0.1)])
+def test_overlapped_slab_operator_equals_one_sweep(stfem, p, nc, number, distort):
+    """dealii-stfem_amd/distributed.py::OverlappedSlabOperator (interface cell layers first, into vectors of their own; interior layers
+    straight into the destination; stfem_planes_move): the same result as one sweep over the slab - what the exchange then completes."""
+    dmod = importlib.import_module("dealii-stfem_amd.distributed")
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 2, 0.05, 1)
+    nb = Alpha.shape[0]
+    mask = 63 & ~48  # a slab in the middle of a partition: both z faces are interfaces
+    verts = stfem.mesh_vertices(nc, distort=distort, seed=3) if distort else None
+    nvx, nvy = nc[0] + 1, nc[1] + 1
+
+    def make_ctx(z0, z1, m):
+        snc = (nc[0], nc[1], z1 - z0)
+        if verts is not None:
+            v = np.asarray(verts).reshape(nc[2] + 1, nvy * nvx * 3)[z0:z1 + 1].reshape(-1)
+            return stfem.MatrixFreeOperator(p, snc, vertices=v, number=number, dirichlet_mask=m)
+        return stfem.MatrixFreeOperator(p, snc, lower=(0, 0, z0 / nc[2]), upper=(1, 1, z1 / nc[2]), number=number, dirichlet_mask=m)
+
+    ctx = make_ctx(0, nc[2], mask)
+    A = stfem.SystemMatrix(ctx, Alpha, Beta)
+    rng = np.random.default_rng(6)
+    X = rng.uniform(-1, 1, (nb, ctx.n_dofs))
+    if number == "float":
+        X = X.astype(np.float32).astype(np.float64)
+    src, ref, dst = stfem.BlockVector(ctx, nb).upload(X), stfem.BlockVector(ctx, nb), stfem.BlockVector(ctx, nb)
+    dst.upload(np.full((nb, ctx.n_dofs), 1e30))  # every entry must be written
+    op = dmod.OverlappedSlabOperator(stfem, ctx, make_ctx, lambda c: stfem.SystemMatrix(c, Alpha, Beta), src, dst, mask)
+    for transpose in (False, True):
+        (A.Tvmult if transpose else A.vmult)(ref, src)
+        op.vmult(transpose=transpose)
+        want, got = ref.download(), dst.download()
+        assert np.linalg.norm(got - want) <= (1e-14 if number == "double" else 1e-6) * np.linalg.norm(want)
