@@ -170,6 +170,12 @@ SIGNATURES = {
     "stfem_stokes_n_face_points": (C.c_int64, [_vp]),
     "stfem_stokes_face_points": (C.c_int, [_vp, _dp]),
     "stfem_stokes_nitsche_rhs": (C.c_int, [_vp, _dp, _vp, _vp, _vp]),
+    "stfem_stokes_pressure_ctx": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "stfem_stokes_pressure_mean_vectors": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "stfem_stokes_pressure_quadrature_points": (C.c_int, [_vp, C.c_int, _dp]),
+    "stfem_stokes_pressure_difference": (C.c_int, [_vp, C.c_int, _vp, _dp, _dp, _vp]),
+    "stfem_stokes_dgp_prolongate": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "stfem_stokes_dgp_restrict": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "stfem_stokes_vanka_create": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32), _dp, _dp, C.POINTER(_vp)]),
     "stfem_stokes_vanka_destroy": (None, [_vp]),
     "stfem_stokes_vanka_n_classes": (C.c_int, [_vp]),

@@ -922,6 +922,10 @@ struct stfem_stokes_ctx {
   // stream of the context's own, forked from and joined to the caller's stream with two events
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  stfem_ctx *pressure_space = nullptr; // scalar context behind the pressure vectors (stfem_stokes_pressure_ctx), made on demand
+  double *d_pq = nullptr;              // exact values at the pressure quadrature points (stfem_stokes_pressure_difference)
+  size_t pq_points = 0;
+  double *d_pred = nullptr;            // its reduction results
   int weak_mask = 0, outflow_mask = 0;
   double penalty1 = 20.0, penalty2 = 10.0;
   BoundaryParams bnd;
@@ -1091,6 +1095,9 @@ void stfem_stokes_destroy(stfem_stokes_ctx *c)
   if (c->d_vertices) (void)hipFree(c->d_vertices);
   if (c->d_g) (void)hipFree(c->d_g);
   if (c->scalar) stfem_ctx_destroy(c->scalar);
+  if (c->pressure_space) stfem_ctx_destroy(c->pressure_space);
+  if (c->d_pq) (void)hipFree(c->d_pq);
+  if (c->d_pred) (void)hipFree(c->d_pred);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1596,6 +1603,257 @@ int stfem_stokes_nitsche_rhs(stfem_stokes_ctx *c, const double *g_at_face_points
   prm.out_u[0] = dst_u; prm.out_p[0] = dst_p;
   prm.wKu[0] = prm.wKp[0] = 1.0;
   return stokes_boundary_launch(c, prm, c->d_g, st);
+}
+
+} // extern "C"
+
+// ---- the pressure space by itself: what the solver around the operator needs of it (tests/tp_03stokes.cc:404-425, 1047-1062,
+// include/exact_solution.h:503-649, the pressure transfer of the Stokes multigrid levels) ----
+extern "C++" {
+namespace {
+// sum JxW (p_h - p)^2 and max |p_h - p| over QGauss(nq)^3 of the cells; blockIdx.x = cell (axis-aligned uniform cells)
+template <bool PDG>
+__global__ __launch_bounds__(64) void pressure_difference_kernel(int ncx, int ncy, int ncz, int nq, double vol, const double *__restrict__ xq,
+                                                                 const double *__restrict__ wq, const double *__restrict__ p,
+                                                                 const double *__restrict__ exact, double *__restrict__ out)
+{
+  const long long cell = blockIdx.x;
+  const int cx = int(cell % ncx), cy = int((cell / ncx) % ncy), cz = int(cell / ((long long)ncx * ncy));
+  const int nq3 = nq * nq * nq;
+  double l2 = 0.0, l8 = 0.0;
+  for (int q = threadIdx.x; q < nq3; q += 64) {
+    const int qx = q % nq, qy = (q / nq) % nq, qz = q / (nq * nq);
+    const double x = xq[qx], y = xq[qy], z = xq[qz];
+    double ph;
+    if (PDG) {
+      const double *c = p + 4 * cell;
+      const double s3 = 1.7320508075688772;
+      ph = c[0] + s3 * (c[1] * (2 * x - 1) + c[2] * (2 * y - 1) + c[3] * (2 * z - 1));
+    } else {
+      const int npx = ncx + 1, npy = ncy + 1;
+      ph = 0.0;
+      for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 2; ++j)
+          for (int i = 0; i < 2; ++i)
+            ph += (i ? x : 1 - x) * (j ? y : 1 - y) * (k ? z : 1 - z) * p[(cx + i) + (long long)npx * ((cy + j) + (long long)npy * (cz + k))];
+    }
+    const double e = ph - exact[cell * nq3 + q];
+    l2 += vol * wq[qx] * wq[qy] * wq[qz] * e * e;
+    l8 = fmax(l8, fabs(e));
+  }
+  __shared__ double s2[64], s8[64];
+  s2[threadIdx.x] = l2; s8[threadIdx.x] = l8;
+  __syncthreads();
+  if (threadIdx.x == 0) { // fixed order: reproducible
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < 64; ++t) { a += s2[t]; b = fmax(b, s8[t]); }
+    out[2 * cell] = a;
+    out[2 * cell + 1] = b;
+  }
+}
+__global__ __launch_bounds__(256) void pressure_difference_finish(long long ncells, const double *__restrict__ part, double *__restrict__ out)
+{
+  __shared__ double s2[256], s8[256];
+  double a = 0.0, b = 0.0;
+  for (long long c = threadIdx.x; c < ncells; c += 256) { a += part[2 * c]; b = fmax(b, part[2 * c + 1]); }
+  s2[threadIdx.x] = a; s8[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double x = 0.0, y = 0.0;
+    for (int t = 0; t < 256; ++t) { x += s2[t]; y = fmax(y, s8[t]); }
+    out[0] = x; out[1] = y;
+  }
+}
+// FE_DGP(1) between a mesh and the mesh of its 2 x 2 x 2 children: the parent's function on child (sx, sy, sz) has the coefficients
+// c0 + sqrt 3 ((sx - 1/2) c1 + (sy - 1/2) c2 + (sz - 1/2) c3), c1 / 2, c2 / 2, c3 / 2 (the embedding MGTwoLevelTransfer prolongates
+// with; its restriction is the transpose).  One thread per coarse cell.
+template <bool RESTRICT>
+__global__ __launch_bounds__(256) void dgp_transfer_kernel(int ncx, int ncy, int ncz, double *__restrict__ dst, const double *__restrict__ src, int add)
+{
+  const long long cc = (long long)blockIdx.x * 256 + threadIdx.x; // coarse cell
+  if (cc >= (long long)ncx * ncy * ncz) return;
+  const int cx = int(cc % ncx), cy = int((cc / ncx) % ncy), cz = int(cc / ((long long)ncx * ncy));
+  const int fx = 2 * ncx, fy = 2 * ncy;
+  const double s3h = 0.8660254037844386; // sqrt 3 / 2
+  double acc[4] = {0, 0, 0, 0};
+  double pc[4] = {0, 0, 0, 0};
+  if (!RESTRICT)
+    for (int j = 0; j < 4; ++j) pc[j] = src[4 * cc + j];
+  for (int sz = 0; sz < 2; ++sz)
+    for (int sy = 0; sy < 2; ++sy)
+      for (int sx = 0; sx < 2; ++sx) {
+        const long long fc = (2 * cx + sx) + (long long)fx * ((2 * cy + sy) + (long long)fy * (2 * cz + sz));
+        const double ox = sx ? s3h : -s3h, oy = sy ? s3h : -s3h, oz = sz ? s3h : -s3h;
+        if (RESTRICT) {
+          const double *f = src + 4 * fc;
+          acc[0] += f[0];
+          acc[1] += ox * f[0] + 0.5 * f[1];
+          acc[2] += oy * f[0] + 0.5 * f[2];
+          acc[3] += oz * f[0] + 0.5 * f[3];
+        } else {
+          double *f = dst + 4 * fc;
+          const double v[4] = {pc[0] + ox * pc[1] + oy * pc[2] + oz * pc[3], 0.5 * pc[1], 0.5 * pc[2], 0.5 * pc[3]};
+          for (int j = 0; j < 4; ++j) f[j] = add ? f[j] + v[j] : v[j];
+        }
+      }
+  if (RESTRICT)
+    for (int j = 0; j < 4; ++j) dst[4 * cc + j] = add ? dst[4 * cc + j] + acc[j] : acc[j];
+}
+} // namespace
+} // extern "C++"
+
+extern "C" {
+
+// The scalar context behind the pressure vectors, for their vector arithmetic (stfem_vector_wrap + stfem_vector_axpby / stfem_dot /
+// stfem_multi_dot ...) and, for FE_Q(1), for everything a FE_Q(1) function has in this library (load vectors, transfers, error norms).
+// FE_Q(1): a degree-1 context on the mesh, no constraints.  FE_DGP(1): the arrays have 4 n_cells entries, which no mesh of this
+// library's continuous elements has in general: the context is a CARRIER - a degree-1 context on 1 x 1 x (n_cells - 1) cells, i.e. with
+// 2 x 2 x n_cells DoFs - good for the vector arithmetic only.  Owned by the Stokes context.
+int stfem_stokes_pressure_ctx(stfem_stokes_ctx *c, stfem_ctx **out)
+{
+  if (!c || !out) return STFEM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!c->pressure_space) {
+    stfem_mesh_desc md;
+    std::memset(&md, 0, sizeof(md));
+    md.device = c->device;
+    md.dirichlet_mask = 0;
+    const long long ncells = (long long)c->nc[0] * c->nc[1] * c->nc[2];
+    if (c->pspace) {
+      if (ncells < 2 || ncells - 1 > 0x7fffffffll) return STFEM_ERR_UNSUPPORTED;
+      md.ncell[0] = md.ncell[1] = 1;
+      md.ncell[2] = int32_t(ncells - 1);
+      for (int d = 0; d < 3; ++d) { md.lower[d] = 0.0; md.upper[d] = 1.0; }
+    } else {
+      for (int d = 0; d < 3; ++d) {
+        md.ncell[d] = c->nc[d];
+        md.lower[d] = c->h_vertices[d];
+        md.upper[d] = c->h_vertices[c->h_vertices.size() - 3 + d];
+      }
+      if (!c->base.cart) md.vertices = c->h_vertices.data();
+    }
+    stfem_space_desc sd{1, 2, 1, 0};
+    const int rc = stfem_ctx_create(&md, &sd, &c->pressure_space);
+    if (rc != STFEM_OK) return rc;
+  }
+  *out = c->pressure_space;
+  return STFEM_OK;
+}
+
+// The constant function and the mean-value functional of the pressure space (host arrays of n_pressure_dofs entries): ones = the
+// coefficients of p = 1, weights = (1, psi_j) so that mean(p) = weights . p / volume (VectorTools::compute_mean_value /
+// add_constant, tests/tp_03stokes.cc:1047-1062).  Axis-aligned uniform meshes.
+int stfem_stokes_pressure_mean_vectors(stfem_stokes_ctx *c, double *ones, double *weights, double *volume)
+{
+  if (!c || !ones || !weights || !volume) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!c->base.cart) return STFEM_ERR_UNSUPPORTED;
+  const double cell = c->base.detJ;
+  const long long ncells = (long long)c->nc[0] * c->nc[1] * c->nc[2];
+  *volume = cell * double(ncells);
+  if (c->pspace) { // psi_0 = 1, the others have zero mean on a box
+    for (long long i = 0; i < c->Np; ++i) { ones[i] = (i & 3) == 0 ? 1.0 : 0.0; weights[i] = (i & 3) == 0 ? cell : 0.0; }
+  } else {
+    for (int k = 0; k < c->ndp[2]; ++k)
+      for (int j = 0; j < c->ndp[1]; ++j)
+        for (int i = 0; i < c->ndp[0]; ++i) {
+          const double wx = (i == 0 || i == c->ndp[0] - 1) ? 0.5 : 1.0, wy = (j == 0 || j == c->ndp[1] - 1) ? 0.5 : 1.0,
+                       wz = (k == 0 || k == c->ndp[2] - 1) ? 0.5 : 1.0;
+          const long long o = i + (long long)c->ndp[0] * (j + (long long)c->ndp[1] * k);
+          ones[o] = 1.0;
+          weights[o] = cell * wx * wy * wz;
+        }
+  }
+  return STFEM_OK;
+}
+
+// quadrature points of QGauss(nq)^3 on the cells, out[cell][q][3], q = qx + nq (qy + nq qz) (axis-aligned uniform meshes)
+int stfem_stokes_pressure_quadrature_points(const stfem_stokes_ctx *c, int nq, double *out)
+{
+  if (!c || !out || nq < 1 || nq > 8) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!c->base.cart) return STFEM_ERR_UNSUPPORTED;
+  std::vector<double> xq, wq;
+  stfem::gauss_rule(nq, xq, wq);
+  double lo[3], h[3];
+  for (int d = 0; d < 3; ++d) { lo[d] = c->h_vertices[d]; h[d] = 1.0 / c->base.hinv[d]; }
+  size_t o = 0;
+  for (int cz = 0; cz < c->nc[2]; ++cz)
+    for (int cy = 0; cy < c->nc[1]; ++cy)
+      for (int cx = 0; cx < c->nc[0]; ++cx)
+        for (int qz = 0; qz < nq; ++qz)
+          for (int qy = 0; qy < nq; ++qy)
+            for (int qx = 0; qx < nq; ++qx, o += 3) {
+              out[o] = lo[0] + h[0] * (cx + xq[qx]);
+              out[o + 1] = lo[1] + h[1] * (cy + xq[qy]);
+              out[o + 2] = lo[2] + h[2] * (cz + xq[qz]);
+            }
+  return STFEM_OK;
+}
+
+// out = { sum JxW (p_h - p)^2, max |p_h - p| } over those points (VectorTools::integrate_difference, L2_norm squared and Linfty_norm);
+// p: device, exact_at_points: host [cell][q].  Synchronous.
+int stfem_stokes_pressure_difference(stfem_stokes_ctx *c, int nq, const double *p, const double *exact_at_points, double out[2], void *stream)
+{
+  if (!c || !p || !exact_at_points || !out || nq < 1 || nq > 8) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!c->base.cart) return STFEM_ERR_UNSUPPORTED;
+  STOKES_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long ncells = (long long)c->nc[0] * c->nc[1] * c->nc[2];
+  const size_t npts = size_t(ncells) * nq * nq * nq;
+  if (c->pq_points < npts) {
+    if (c->d_pq) STOKES_TRY(hipFree(c->d_pq));
+    if (c->d_pred) STOKES_TRY(hipFree(c->d_pred));
+    c->d_pq = c->d_pred = nullptr;
+    c->pq_points = 0;
+    if (hipMalloc(&c->d_pq, (npts + 16) * sizeof(double)) != hipSuccess || hipMalloc(&c->d_pred, (2 * size_t(ncells) + 2) * sizeof(double)) != hipSuccess)
+      return STFEM_ERR_OUT_OF_MEMORY;
+    c->pq_points = npts;
+  }
+  std::vector<double> xq, wq;
+  stfem::gauss_rule(nq, xq, wq);
+  std::vector<double> rule(xq);
+  rule.insert(rule.end(), wq.begin(), wq.end());
+  STOKES_TRY(hipMemcpyAsync(c->d_pq, exact_at_points, npts * sizeof(double), hipMemcpyHostToDevice, st));
+  STOKES_TRY(hipMemcpyAsync(c->d_pq + npts, rule.data(), rule.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  (void)hipGetLastError();
+  if (c->pspace)
+    hipLaunchKernelGGL(pressure_difference_kernel<true>, dim3((unsigned)ncells), dim3(64), 0, st, c->nc[0], c->nc[1], c->nc[2], nq, c->base.detJ,
+                       c->d_pq + npts, c->d_pq + npts + nq, p, c->d_pq, c->d_pred);
+  else
+    hipLaunchKernelGGL(pressure_difference_kernel<false>, dim3((unsigned)ncells), dim3(64), 0, st, c->nc[0], c->nc[1], c->nc[2], nq, c->base.detJ,
+                       c->d_pq + npts, c->d_pq + npts + nq, p, c->d_pq, c->d_pred);
+  hipLaunchKernelGGL(pressure_difference_finish, dim3(1), dim3(256), 0, st, ncells, c->d_pred, c->d_pred + 2 * ncells);
+  if (hipGetLastError() != hipSuccess) return STFEM_ERR_HIP;
+  STOKES_TRY(hipMemcpyAsync(out, c->d_pred + 2 * ncells, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  STOKES_TRY(hipStreamSynchronize(st));
+  return STFEM_OK;
+}
+
+// The FE_DGP(1) pressure between a mesh and the mesh with twice the cells per direction (the pressure variable's MGTwoLevelTransfer
+// of the Stokes multigrid levels, include/stmg.h:557-600): prolongate: fine (=, +=) embedding of coarse; restrict: coarse (=, +=) its
+// transpose applied to fine.  FE_Q(1) pressures use stfem_transfer_* on stfem_stokes_pressure_ctx.
+int stfem_stokes_dgp_prolongate(stfem_stokes_ctx *fine, stfem_stokes_ctx *coarse, double *dst_fine, const double *src_coarse, int add, void *stream)
+{
+  if (!fine || !coarse || !dst_fine || !src_coarse) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!fine->pspace || !coarse->pspace) return STFEM_ERR_UNSUPPORTED;
+  for (int d = 0; d < 3; ++d)
+    if (fine->nc[d] != 2 * coarse->nc[d]) return STFEM_ERR_SHAPE_MISMATCH;
+  STOKES_TRY(hipSetDevice(fine->device));
+  const long long nc = (long long)coarse->nc[0] * coarse->nc[1] * coarse->nc[2];
+  hipLaunchKernelGGL(dgp_transfer_kernel<false>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), coarse->nc[0],
+                     coarse->nc[1], coarse->nc[2], dst_fine, src_coarse, add);
+  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+int stfem_stokes_dgp_restrict(stfem_stokes_ctx *fine, stfem_stokes_ctx *coarse, double *dst_coarse, const double *src_fine, int add, void *stream)
+{
+  if (!fine || !coarse || !dst_coarse || !src_fine) return STFEM_ERR_INVALID_ARGUMENT;
+  if (!fine->pspace || !coarse->pspace) return STFEM_ERR_UNSUPPORTED;
+  for (int d = 0; d < 3; ++d)
+    if (fine->nc[d] != 2 * coarse->nc[d]) return STFEM_ERR_SHAPE_MISMATCH;
+  STOKES_TRY(hipSetDevice(fine->device));
+  const long long nc = (long long)coarse->nc[0] * coarse->nc[1] * coarse->nc[2];
+  hipLaunchKernelGGL(dgp_transfer_kernel<true>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), coarse->nc[0],
+                     coarse->nc[1], coarse->nc[2], dst_coarse, src_fine, add);
+  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
 }
 
 } // extern "C"

@@ -13,15 +13,16 @@ namespace stfem {
 // the pressure a FE_Q(1) function without constraints.  Their contexts serve the vector arithmetic, the load vectors, the
 // interpolation and the error norms of the Stokes vectors (VectorTools::* per variable in the reference).
 struct StokesSpaces {
-  std::shared_ptr<Context> q2, q1;
-  explicit StokesSpaces(const Mesh &mesh)
+  std::shared_ptr<Context> q2, q1; // q1: the pressure space's context (FE_Q(1): a real one; FE_DGP(1): a carrier for the vector arithmetic)
+  stfem_stokes_ctx *stokes;
+  StokesSpaces(const Mesh &mesh, stfem_stokes_ctx *stokes_) : stokes(stokes_)
   {
     MatrixFreeOperator<3, 1, double> a(mesh, 2, 0.0, 1.0);
     q2 = a.context();
-    Mesh m1 = mesh;
-    m1.dirichlet_mask = 0;
-    MatrixFreeOperator<3, 1, double> b(m1, 1, 1.0, 0.0);
-    q1 = b.context();
+    stfem_ctx *pc = nullptr;
+    check(stfem_stokes_pressure_ctx(stokes, &pc), "stfem_stokes_pressure_ctx");
+    q1 = std::make_shared<Context>(pc, false);
+    q1->degree = 1;
   }
   // z-slab partition (the mesh is this rank's slab, interface faces taken out of its Dirichlet mask): the operator leaves partial
   // sums in the interface planes of every velocity component and of the pressure (tests/test_gpu_stokes.py::
@@ -210,7 +211,7 @@ public:
     : data_(data), slice_(slice), Alpha_(Alpha), Beta_(Beta)
   {
     if (n_levels < 1) throw std::invalid_argument("GMGStokes: at least one level");
-    if (dg_pressure) throw Error(STFEM_ERR_UNSUPPORTED, "GMGStokes: FE_DGP pressure transfers are not built");
+    dg_ = dg_pressure;
     levels_.resize(n_levels);
     for (unsigned l = 0; l < n_levels; ++l) {
       Level &L = levels_[l];
@@ -220,8 +221,9 @@ public:
         if (mesh.ncell[d] % f) throw std::invalid_argument("GMGStokes: the cell counts must be divisible by 2^(levels - 1)");
         L.mesh.ncell[d] = mesh.ncell[d] / f;
       }
-      L.K = std::make_unique<StokesMatrixFreeOperator<dim, double>>(L.mesh, 2, viscosity, weak_boundary_ids);
-      L.spaces = std::make_shared<StokesSpaces>(L.mesh);
+      L.K = std::make_unique<StokesMatrixFreeOperator<dim, double>>(L.mesh, 2, viscosity, weak_boundary_ids, std::set<boundary_id>(), 20.0, 10.0, 0.0, 0.0, 0.0,
+                                                                   dg_pressure);
+      L.spaces = std::make_shared<StokesSpaces>(L.mesh, L.K->handle());
       L.A = std::make_unique<SystemMatrixStokes<dim, double>>(*L.K, Alpha_, Beta_, slice_);
       L.system = std::make_unique<StokesSystem<dim, double>>(*L.A, L.spaces, L.K->handle(), slice_);
       L.vanka = std::make_unique<PreconditionVankaStokes<double>>(*L.K, Alpha_, Beta_, slice_);
@@ -232,7 +234,7 @@ public:
       L.system->initialize_dof_vector(L.t);
       if (l > 0) {
         L.tr_u = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q2, levels_[l - 1].spaces->q2);
-        L.tr_p = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q1, levels_[l - 1].spaces->q1);
+        if (!dg_) L.tr_p = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q1, levels_[l - 1].spaces->q1);
       }
     }
   }
@@ -316,17 +318,27 @@ private:
     axpby(1.0, L.defect, -1.0, L.t);
     set_zero(C.defect);
     for (unsigned b = 0; b < slice_.n_blocks(); ++b) { // MGTwoLevelBlockTransfer::restrict_and_add: block by block with its variable's transfer
+      if (slice_.decompose(b)[1] == 1 && dg_) {
+        check(stfem_stokes_dgp_restrict(L.K->handle(), C.K->handle(), C.defect.blocks()[b].data(), L.t.blocks()[b].data(), 1, nullptr), "GMGStokes: restrict_and_add");
+        continue;
+      }
       const MGTwoLevelTransfer<double> &tr = slice_.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
       check(stfem_transfer_restrict(tr.handle(), C.defect.view(b).handle(), L.t.view(b).handle(), 1, nullptr), "GMGStokes: restrict_and_add");
     }
     level_v_step(level - 1);
     for (unsigned b = 0; b < slice_.n_blocks(); ++b) {
+      if (slice_.decompose(b)[1] == 1 && dg_) {
+        check(stfem_stokes_dgp_prolongate(L.K->handle(), C.K->handle(), L.solution.blocks()[b].data(), C.solution.blocks()[b].data(), 1, nullptr),
+              "GMGStokes: prolongate_and_add");
+        continue;
+      }
       const MGTwoLevelTransfer<double> &tr = slice_.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
       check(stfem_transfer_prolongate(tr.handle(), L.solution.view(b).handle(), C.solution.view(b).handle(), 1, nullptr), "GMGStokes: prolongate_and_add");
     }
     smooth(level, false);
   }
   AdditionalData data_;
+  bool dg_ = false;
   BlockSlice slice_;
   FullMatrix<double> Alpha_, Beta_;
   std::vector<Level> levels_;
@@ -366,6 +378,55 @@ double estimate_relaxation_stokes(const System &A, const PreconditionVankaStokes
   const double beta = 1.2 * lambda, alpha = smoothing_range > 1.0 ? beta / smoothing_range : std::min(0.9 * beta, 1.0);
   return 2.0 / (alpha + beta);
 }
+
+// ErrorCalculator (include/exact_solution.h:503-649) for the pressure variable in either pressure space: the temporal Lagrange
+// combination of the pressure blocks (evaluate_numerical_solution), then stfem_stokes_pressure_difference with QGauss(nq)^3
+class PressureErrorCalculator {
+public:
+  PressureErrorCalculator(TimeStepType type, unsigned time_degree, int nq_space, const std::shared_ptr<StokesSpaces> &spaces, const PointFunction &exact)
+    : type(type), time_degree(time_degree), nq(nq_space), spaces(spaces), exact(exact), nodes(time_points(type, time_degree)), tq(time_degree + 1),
+      tw(time_degree + 1)
+  {
+    check(stfem_gauss_rule(int(time_degree + 1), tq.data(), tw.data()), "stfem_gauss_rule");
+    numeric.reinit(spaces->q1, 1);
+    const size_t ncells = size_t(stfem_n_cells(spaces->q2->h));
+    qpoints.resize(ncells * nq * nq * nq * 3);
+    check(stfem_stokes_pressure_quadrature_points(spaces->stokes, nq, qpoints.data()), "stfem_stokes_pressure_quadrature_points");
+  }
+  // {L2^2 contribution, Linfty} of the slab; x: the pressure blocks of the time dofs (views on the pressure space), prev: the previous one
+  std::array<double, 2> evaluate_error(double time, double time_step, const BlockVectorT<double> &x, const BlockVectorT<double> &prev)
+  {
+    std::array<double, 2> err{0.0, -1.0};
+    const unsigned nt_dofs = type == TimeStepType::DG ? time_degree + 1 : time_degree;
+    std::vector<double> pe;
+    for (unsigned q = 0; q < tq.size(); ++q) {
+      const std::vector<double> L = lagrange_values(nodes, tq[q]);
+      set_zero(numeric);
+      if (type == TimeStepType::DG) {
+        for (unsigned i = 0; i < nt_dofs; ++i) axpby(L[i], block_view(x, i), 1.0, numeric);
+      } else {
+        axpby(L[0], prev, 1.0, numeric);
+        for (unsigned i = 1; i <= time_degree; ++i) axpby(L[i], block_view(x, i - 1), 1.0, numeric);
+      }
+      exact(time + tq[q] * time_step, qpoints, pe);
+      double out[2];
+      check(stfem_stokes_pressure_difference(spaces->stokes, nq, static_cast<const double *>(stfem_vector_block(numeric.handle(), 0)), pe.data(), out, nullptr),
+            "stfem_stokes_pressure_difference");
+      err[0] += time_step * tw[q] * out[0];
+      err[1] = std::max(err[1], out[1]);
+    }
+    return err;
+  }
+
+private:
+  TimeStepType type;
+  unsigned time_degree;
+  int nq;
+  std::shared_ptr<StokesSpaces> spaces;
+  PointFunction exact;
+  std::vector<double> nodes, tq, tw, qpoints;
+  BlockVectorT<double> numeric;
+};
 
 // A vector function of (x, t) at a list of points: out[c][i] = f_c(points[3 i .. 3 i + 2], t)
 using VectorPointFunction = std::function<void(double time, const std::vector<double> &points, std::array<std::vector<double>, 3> &out)>;
@@ -414,15 +475,13 @@ public:
       axpby(1.0, prev.view(slice.decompose(i)[1]), 0.0, x.view(i));
     solver.solve(matrix, x, rhs, preconditioner);
     if (zero_mean) {
-      if (!weights.handle()) { // 1^T M_p: the load vector of the constant one; |Omega| = 1^T M_p 1
+      if (!weights.handle()) { // mean(p) = weights . p / |Omega|, p -= mean * ones (VectorTools::compute_mean_value / add_constant)
         weights.reinit(sp.q1, 1);
         ones.reinit(sp.q1, 1);
-        const size_t nq = size_t(stfem_n_cells(sp.q1->h)) * 8;
-        std::vector<double> one(nq, 1.0);
-        check(stfem_integrate_rhs(sp.q1->h, 2, one.data(), weights.handle(), 0, nullptr), "stfem_integrate_rhs");
-        std::vector<std::vector<double>> h1(1, std::vector<double>(ones.block_size(), 1.0));
+        std::vector<std::vector<double>> h1(1, std::vector<double>(ones.block_size())), hw(1, std::vector<double>(ones.block_size()));
+        check(stfem_stokes_pressure_mean_vectors(sp.stokes, h1[0].data(), hw[0].data(), &volume), "stfem_stokes_pressure_mean_vectors");
         ones.copy_from_host(h1);
-        volume = dot(weights, ones);
+        weights.copy_from_host(hw);
       }
       for (unsigned a = 0; a < nt_dofs; ++a) {
         BlockVectorT<double> &p = x.view(slice.index(0, 1, a));

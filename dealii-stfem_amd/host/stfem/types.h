@@ -151,8 +151,9 @@ struct Context {
   // general meshes on a partition: the same slab plus one ghost cell layer per interface (MatrixFreeOperator::set_ghost_layers):
   // what the cell-patch smoother builds its blocks on (stmg.h:688-689: locally owned and ghost cells)
   std::shared_ptr<Context> extended;
-  explicit Context(stfem_ctx *c) : h(c) {}
-  ~Context() { stfem_ctx_destroy(h); }
+  bool owned = true; // false: the handle belongs to another object (the pressure space of a Stokes context)
+  explicit Context(stfem_ctx *c, bool owned = true) : h(c), owned(owned) {}
+  ~Context() { if (owned) stfem_ctx_destroy(h); }
   Context(const Context &) = delete;
   Context &operator=(const Context &) = delete;
   bool partitioned() const { return comm && (lower_rank >= 0 || upper_rank >= 0); }

@@ -8,7 +8,7 @@
 // host/stfem/stokes_solver.h: <levels> space levels, relaxation sweeps of the Vanka smoother on every level, 2^(levels - 1 - l) smoothing
 // steps on level l); the errors do not depend on the preconditioner, the iteration counts do.
 // Usage: stokes_convergence <type 0 = cG | 1 = dG> <k> <refinement> [vanka sweeps = 3] [omega = 0: estimated] [viscosity = 1] [cells per direction]
-//                           [end_time = 1] [mg=<levels>]
+//                           [end_time = 1] [mg=<levels>] [dg=1]
 // Prints: cells u-dofs p-dofs t-dofs  u:Linf-Linf  u:L2-L2  u:L2-H1semi  p:L2-L2  gmres-iterations-per-solve
 #include "stfem/stokes_solver.h"
 
@@ -32,9 +32,11 @@ inline double d2B(double s) { return -4 * PI * PI * B(s); }
 int main(int argc_all, char **argv_all)
 {
   unsigned mg_levels = 0;
+  bool dg_pressure = false; // dg=1: FE_DGP(1) pressure, the reference's default (tests/json/stokes.json: dGPressure = true)
   std::vector<char *> pos;
   for (int i = 0; i < argc_all; ++i) {
     if (i > 0 && std::strncmp(argv_all[i], "mg=", 3) == 0) mg_levels = unsigned(std::atoi(argv_all[i] + 3));
+    else if (i > 0 && std::strncmp(argv_all[i], "dg=", 3) == 0) dg_pressure = std::atoi(argv_all[i] + 3) != 0;
     else pos.push_back(argv_all[i]);
   }
   const int argc = int(pos.size());
@@ -53,8 +55,8 @@ int main(int argc_all, char **argv_all)
   try {
     Mesh mesh;
     mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = n;
-    StokesMatrixFreeOperator<3, double> K(mesh, 2, nu);
-    auto spaces = std::make_shared<StokesSpaces>(mesh);
+    StokesMatrixFreeOperator<3, double> K(mesh, 2, nu, std::set<boundary_id>(), std::set<boundary_id>(), 20.0, 10.0, 0.0, 0.0, 0.0, dg_pressure);
+    auto spaces = std::make_shared<StokesSpaces>(mesh, K.handle());
     const unsigned nt = type == TimeStepType::CGP ? k : k + 1;
     const BlockSlice slice(1, 2, nt), slice1(1, 2, 1);
     const auto w = get_fe_time_weights_stokes<double>(type, k, tau, 1); // Alpha, Beta, Gamma, Zeta (fe_time.h:1242-1285)
@@ -109,7 +111,6 @@ int main(int argc_all, char **argv_all)
       out.resize(p.size() / 3);
       for (size_t i = 0; i < out.size(); ++i) out[i] = std::sin(t) * std::cos(PI * p[3 * i]) * std::cos(PI * p[3 * i + 1]) * std::cos(PI * p[3 * i + 2]);
     };
-    const PointFunction no_gradient = [](double, const std::vector<double> &p, std::vector<double> &out) { out.assign(p.size(), 0.0); };
 
     // the preconditioner behind one interface: relaxation sweeps on the finest level, or one V-cycle
     std::unique_ptr<GMGStokes<3>> gmg;
@@ -117,7 +118,7 @@ int main(int argc_all, char **argv_all)
       GMGStokes<3>::AdditionalData ad;
       ad.smoothing_degree = sweeps;
       ad.relaxation = omega_arg;
-      gmg = std::make_unique<GMGStokes<3>>(mesh, mg_levels, nu, w[0], w[1], slice, ad);
+      gmg = std::make_unique<GMGStokes<3>>(mesh, mg_levels, nu, w[0], w[1], slice, ad, std::set<boundary_id>(), dg_pressure);
       for (unsigned l = 0; l < gmg->n_levels(); ++l) std::fprintf(stderr, "level %u: relaxation %.4f\n", l, gmg->relaxation(l));
     } else
       std::fprintf(stderr, "relaxation %.4f\n", omega);
@@ -134,7 +135,7 @@ int main(int argc_all, char **argv_all)
     // ErrorCalculator (exact_solution.h:503-649): QGauss(k + 1) in time; QGauss(3) per direction for the velocity components, QGauss(2) for the pressure
     std::vector<ErrorCalculator<double>> err_u;
     for (int c = 0; c < 3; ++c) err_u.emplace_back(type, k, 3, spaces->q2, exact_u(c), exact_grad_u(c));
-    ErrorCalculator<double> err_p(type, k, 2, spaces->q1, exact_p, no_gradient);
+    PressureErrorCalculator err_p(type, k, 2, spaces, exact_p);
 
     StokesBlockVector x, rhs, prev;
     x.reinit(spaces, K.handle(), slice);
@@ -171,7 +172,7 @@ int main(int argc_all, char **argv_all)
         xp.wrap(spaces->q1, ptrs.data(), nt);
         void *q[1] = {prev.blocks()[1].data()};
         pp.wrap(spaces->q1, q, 1);
-        l2p += err_p.evaluate_error(time, tau, xp, pp, 1)[0];
+        l2p += err_p.evaluate_error(time, tau, xp, pp)[0];
       }
       axpby(1.0, x.view(slice.index(0, 0, nt - 1)), 0.0, prev.view(0));
       axpby(1.0, x.view(slice.index(0, 1, nt - 1)), 0.0, prev.view(1));

@@ -1,6 +1,6 @@
 // C++ caller of the Stokes multigrid mirror (GMGStokes, host/stfem/stokes_solver.h): one V-cycle applied to seeded vectors, written
 // out for the Python test that compares it with the numpy V-cycle of oracle/stmg_oracle.py on dense level matrices.
-//   test_host_stokes_mg n levels type r viscosity smoothing_degree omega variable out.bin
+//   test_host_stokes_mg n levels type r viscosity smoothing_degree omega variable out.bin [dg_pressure]
 #include "stfem/stokes_solver.h"
 
 #include <cstdio>
@@ -11,7 +11,7 @@ using namespace stfem;
 
 int main(int argc, char **argv)
 {
-  if (argc != 10) return 2;
+  if (argc != 10 && argc != 11) return 2;
   try {
     Mesh mesh;
     mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = std::atoi(argv[1]);
@@ -26,7 +26,8 @@ int main(int argc, char **argv)
     const unsigned nt = type == TimeStepType::CGP ? r : r + 1;
     const BlockSlice slice(1, 2, nt);
     const auto w = get_fe_time_weights_stokes<double>(type, r, 1.0 / 16, 1);
-    GMGStokes<3> gmg(mesh, levels, nu, w[0], w[1], slice, ad);
+    const bool dg = argc == 11 && std::atoi(argv[10]) != 0;
+    GMGStokes<3> gmg(mesh, levels, nu, w[0], w[1], slice, ad, std::set<boundary_id>(), dg);
     StokesBlockVector x, y;
     gmg.finest_system().initialize_dof_vector(x);
     gmg.finest_system().initialize_dof_vector(y);

@@ -451,6 +451,24 @@ int stfem_stokes_face_points(const stfem_stokes_ctx *ctx, double *out);
 int stfem_stokes_nitsche_rhs(stfem_stokes_ctx *ctx, const double *g_at_face_points, double *dst_u, double *dst_p, void *stream);
 const char *stfem_stokes_last_hip_error(void);
 
+/* The pressure space by itself - what the solver around the operator needs of it (tests/tp_03stokes.cc:404-425, 1047-1062;
+ * include/exact_solution.h:503-649; the pressure transfer of the Stokes multigrid levels, include/stmg.h:557-600).
+ *   pressure_ctx: the scalar context behind the pressure vectors, owned by the Stokes context: wrap pressure arrays as its one-block
+ *       vectors (stfem_vector_wrap) for the vector arithmetic.  FE_Q(1): a degree-1 context on the mesh without constraints - load
+ *       vectors, error norms and space transfers of a FE_Q(1) function work on it too.  FE_DGP(1): a CARRIER with 4 n_cells DoFs (a
+ *       degree-1 context on 1 x 1 x (n_cells - 1) cells): vector arithmetic only.
+ *   pressure_mean_vectors: host arrays of n_pressure_dofs entries: ones = coefficients of the constant 1, weights = (1, psi_j), and the
+ *       volume: mean(p) = weights . p / volume (VectorTools::compute_mean_value / add_constant).  Axis-aligned uniform meshes.
+ *   pressure_quadrature_points / pressure_difference: QGauss(nq)^3 on the cells, out[cell][q][3]; { sum JxW (p_h - p)^2, max |p_h - p| }
+ *       for exact values at those points (host) and a device pressure array, both pressure spaces (VectorTools::integrate_difference).
+ *   dgp_prolongate / dgp_restrict: FE_DGP(1) between a mesh and the mesh with twice the cells per direction (embedding / transpose). */
+int stfem_stokes_pressure_ctx(stfem_stokes_ctx *ctx, stfem_ctx **out);
+int stfem_stokes_pressure_mean_vectors(stfem_stokes_ctx *ctx, double *ones, double *weights, double *volume);
+int stfem_stokes_pressure_quadrature_points(const stfem_stokes_ctx *ctx, int nq, double *out);
+int stfem_stokes_pressure_difference(stfem_stokes_ctx *ctx, int nq, const double *p, const double *exact_at_points, double out[2], void *stream);
+int stfem_stokes_dgp_prolongate(stfem_stokes_ctx *fine, stfem_stokes_ctx *coarse, double *dst_fine, const double *src_coarse, int add, void *stream);
+int stfem_stokes_dgp_restrict(stfem_stokes_ctx *fine, stfem_stokes_ctx *coarse, double *dst_coarse, const double *src_fine, int add, void *stream);
+
 /* PreconditionVanka over a BlockSlice with two variables (reference include/stmg.h:626-738, 832-872, as tests/tp_03stokes.cc:537-540,
  * 714-726 creates it: K_mask empty, M_mask(0, 0) only): per cell the inverse of
  *     B((i, k), (j, l)) = valence(k) * (Alpha(i, j) K_{iv,jv}(k, l) + [iv = jv = velocity] Beta(i, j) M(k, l)),

@@ -230,15 +230,16 @@ def stokes3d_force(X, Y, Z, t, nu):
     return f1, f2, f3
 
 
-def stokes_convergence_row_3d(ttype, k, refinement, nu=1.0):
+def stokes_convergence_row_3d(ttype, k, refinement, nu=1.0, dg_pressure=False):
     """(u: L-inf L-inf, L2 L2, L2 H1-semi; p: L2 L2) of the solution above on the unit cube, FE_Q(2)^3 x FE_Q(1) x {cG, dG}(k), 2^refinement
-    cells per direction, tau = 2^-(refinement + 1), homogeneous Dirichlet velocity on the whole boundary, one time step per solve."""
+    cells per direction, tau = 2^-(refinement + 1), homogeneous Dirichlet velocity on the whole boundary, one time step per solve.
+    dg_pressure: FE_DGP(1) instead of FE_Q(1) (tests/tp_03stokes.cc:83-86, the reference's default)."""
     n = 2 ** refinement
     h = 1.0 / n
     tau = 2.0 ** -(refinement + 1)
     nc = (n, n, n)
     verts = np.array([[i * h, j * h, kk * h] for kk in range(n + 1) for j in range(n + 1) for i in range(n + 1)], dtype=float)
-    so = o.StokesOracle(nc, verts, 0, nu)
+    so = o.StokesOracle(nc, verts, 0, nu, dg_pressure=dg_pressure)
     Nu, Np = so.n_u, so.n_p
     ndu, ndp = 2 * n + 1, n + 1
     ntot = 3 * Nu + Np
@@ -327,21 +328,34 @@ def stokes_convergence_row_3d(ttype, k, refinement, nu=1.0):
         return l2, l8, h1
 
     def errors_p(pf, t):
-        P = pf.reshape(ndp, ndp, ndp)
+        P = pf.reshape(n, n, n, 4) if dg_pressure else pf.reshape(ndp, ndp, ndp)
         l2 = 0.0
         W = h ** 3 * np.einsum("i,j,k->ijk", ewp, ewp, ewp)
+        lg = np.sqrt(3.0) * (2 * ep - 1)  # deal.II's Legendre basis of FE_DGP(1): 1, l(xi), l(eta), l(zeta)
         for cz in range(n):
             for cy in range(n):
                 for cx in range(n):
                     X, Y, Zc = h * (cx + ep)[None, None, :], h * (cy + ep)[None, :, None], h * (cz + ep)[:, None, None]
-                    ph = np.einsum("ac,bd,ef,cdf->abe", Ep, Ep, Ep, P[cz:cz + 2, cy:cy + 2, cx:cx + 2])
+                    if dg_pressure:
+                        c = P[cz, cy, cx]
+                        ph = c[0] + c[1] * lg[None, None, :] + c[2] * lg[None, :, None] + c[3] * lg[:, None, None]
+                    else:
+                        ph = np.einsum("ac,bd,ef,cdf->abe", Ep, Ep, Ep, P[cz:cz + 2, cy:cy + 2, cx:cx + 2])
                     l2 += np.sum(W * (ph - stokes3d_exact_p(X, Y, Zc, t)) ** 2)
         return l2
 
-    # mean of a FE_Q(1) function: 1^T M_p p / |Omega| with the exact Q1 mass (trapezoid weights per direction)
-    w1 = np.full(ndp, h)
-    w1[0] = w1[-1] = h / 2
-    mean_w = np.einsum("i,j,k->ijk", w1, w1, w1).ravel()
+    # mean value: (1, psi_j) p_j / |Omega|; FE_Q(1): the exact mass applied to 1 (trapezoid weights per direction); FE_DGP(1): psi_0 = 1
+    # and the other functions have zero mean on a box.  The shift subtracts the mean times the coefficients of the constant 1.
+    if dg_pressure:
+        mean_w = np.zeros(Np)
+        mean_w[0::4] = h ** 3
+        one_p = np.zeros(Np)
+        one_p[0::4] = 1.0
+    else:
+        w1 = np.full(ndp, h)
+        w1[0] = w1[-1] = h / 2
+        mean_w = np.einsum("i,j,k->ijk", w1, w1, w1).ravel()
+        one_p = np.ones(Np)
     prev_u, prev_p = np.zeros(NU), np.zeros(NP)
     time = 0.0
     acc_l2 = acc_h1 = acc_p = 0.0
@@ -366,7 +380,7 @@ def stokes_convergence_row_3d(ttype, k, refinement, nu=1.0):
         sol = np.zeros(N)
         sol[keep] = scipy.linalg.lu_solve(lu, rhs[keep])
         xu = [sol[ub(a)] for a in range(nt)]
-        xp = [sol[pb(a)] - np.dot(mean_w, sol[pb(a)]) for a in range(nt)]
+        xp = [sol[pb(a)] - np.dot(mean_w, sol[pb(a)]) * one_p for a in range(nt)]
         for q in range(k + 1):
             if ttype == o.DG:
                 uf = sum(Ltime[q, i] * xu[i] for i in range(nt))

@@ -22,17 +22,37 @@ def _exe(name):
     return exe
 
 
-@pytest.mark.parametrize("n,levels,ttype,r,nu,degree,omega,variable", [
-    (4, 2, 0, 1, 1.0, 1, 0.6, 1),    # cG(1): one time dof; 4^3 -> 2^3 cells
-    (4, 2, 1, 1, 0.5, 2, 0.5, 1),    # dG(1): two time dofs, two sweeps per smoothing step (a third level would be one cell: singular blocks)
-    (4, 2, 0, 2, 1.0, 1, 0.6, 0),    # cG(2), one smoothing step on every level
+def _dgp_prolongation(ncc):
+    """FE_DGP(1) (deal.II's Legendre basis) of a mesh embedded into the mesh of its 2 x 2 x 2 children, cell by cell: with
+    xi = (s + xi') / 2 the parent's l(xi) = sqrt 3 (2 xi - 1) is l(xi') / 2 + sqrt 3 (s - 1 / 2) on child s"""
+    ncf = tuple(2 * c for c in ncc)
+    rows, cols, vals = [], [], []
+    s3h = np.sqrt(3.0) / 2
+    for cz in range(ncf[2]):
+        for cy in range(ncf[1]):
+            for cx in range(ncf[0]):
+                f = 4 * (cx + ncf[0] * (cy + ncf[1] * cz))
+                c = 4 * ((cx // 2) + ncc[0] * ((cy // 2) + ncc[1] * (cz // 2)))
+                off = [s3h if (q % 2) else -s3h for q in (cx, cy, cz)]
+                rows += [f, f, f, f, f + 1, f + 2, f + 3]
+                cols += [c, c + 1, c + 2, c + 3, c + 1, c + 2, c + 3]
+                vals += [1.0, off[0], off[1], off[2], 0.5, 0.5, 0.5]
+    nf, ncl = 4 * ncf[0] * ncf[1] * ncf[2], 4 * ncc[0] * ncc[1] * ncc[2]
+    return sp.coo_matrix((vals, (rows, cols)), shape=(nf, ncl)).tocsr()
+
+
+@pytest.mark.parametrize("n,levels,ttype,r,nu,degree,omega,variable,dg", [
+    (4, 2, 0, 1, 1.0, 1, 0.6, 1, 0),    # cG(1): one time dof; 4^3 -> 2^3 cells
+    (4, 2, 1, 1, 0.5, 2, 0.5, 1, 0),    # dG(1): two time dofs, two sweeps per smoothing step (a third level would be one cell: singular blocks)
+    (4, 2, 0, 2, 1.0, 1, 0.6, 0, 0),    # cG(2), one smoothing step on every level
+    (4, 2, 0, 1, 1.0, 1, 0.4, 1, 1),    # FE_DGP(1) pressure (the reference's default): the pressure transfer is the cell-wise embedding
 ])
-def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variable, tmp_path):
+def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variable, dg, tmp_path):
     from oracle import oracle as o, stmg_oracle as mg, vanka_oracle
     import importlib
     stfem = importlib.import_module("dealii-stfem_amd")
     out = str(tmp_path / "vc.bin")
-    res = subprocess.run([_exe("test_host_stokes_mg"), str(n), str(levels), str(ttype), str(r), str(nu), str(degree), str(omega), str(variable), out],
+    res = subprocess.run([_exe("test_host_stokes_mg"), str(n), str(levels), str(ttype), str(r), str(nu), str(degree), str(omega), str(variable), out, str(dg)],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     raw = np.fromfile(out, dtype=np.uint8)
@@ -54,7 +74,7 @@ def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variabl
         nl = n >> (levels - 1 - l)
         nc = (nl, nl, nl)
         verts = stfem.mesh_vertices(nc)
-        so = o.StokesOracle(nc, verts, 63, nu)
+        so = o.StokesOracle(nc, verts, 63, nu, dg_pressure=bool(dg))
         Nu, Np = so.n_u, so.n_p
         bs = [3 * Nu] * nt + [Np] * nt
         off = np.concatenate([[0], np.cumsum(bs)])
@@ -67,7 +87,7 @@ def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variabl
                 col = so.st_vmult(Alpha, Beta, 1, nt, e)
                 A[:, off[b] + j] = np.concatenate(col)
                 e[b][j] = 0.0
-        vk = vanka_oracle.StokesVankaOracle(nc, verts, 63, nu, var, Alpha, Beta)
+        vk = vanka_oracle.StokesVankaOracle(nc, verts, 63, nu, var, Alpha, Beta, dg_pressure=bool(dg))
 
         def smoother(rv, vk=vk, off=off):
             return np.concatenate(vk.vmult([rv[off[b]:off[b + 1]] for b in range(nb)]))
@@ -76,7 +96,7 @@ def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variabl
         if l > 0:
             ncc = (nl // 2,) * 3
             Pu = mg.space_prolongation(2, nc, 63, 2, ncc, 63)
-            Pp = mg.space_prolongation(1, nc, 0, 1, ncc, 0)
+            Pp = _dgp_prolongation(ncc) if dg else mg.space_prolongation(1, nc, 0, 1, ncc, 0)
             blocks = [sp.block_diag([Pu, Pu, Pu]) if v == 0 else Pp for v in var]
             P = sp.block_diag(blocks).tocsr()
             transfers.append((P, P.T.tocsr()))
