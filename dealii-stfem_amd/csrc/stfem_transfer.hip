@@ -173,6 +173,72 @@ cell_prolongate_kernel(T *__restrict__ out, const T *__restrict__ in, long long 
   }
 }
 
+// The passes along y and z of the prolongation in ONE kernel (same embedding matrix along both axes): a thread takes one coarse cell of
+// the (y, z) plane at its x index, loads its (PC + 1)^2 coarse values once and writes the R^2 (+ the upper ends at the mesh boundary)
+// fine values they produce - the (fine x, fine y, coarse z) intermediate of the three-pass form (4 coarse-vector sizes written and
+// read again for an h-transfer) never exists: 21 instead of 29 coarse-vector sizes of traffic.
+// in: [nx][PC ncy + 1][PC ncz + 1], out: [nx][R ncy + 1][R ncz + 1], x contiguous.
+template <typename T, int PC, int R>
+__global__ void __launch_bounds__(256)
+cell_prolongate_yz_kernel(T *__restrict__ out, const T *__restrict__ in, int nx, int ncy, int ncz, long long total, const CellMat<T> m, int flags_y,
+                          int flags_z, int add)
+{
+  const long long n_cy = (long long)PC * ncy + 1, n_fy = (long long)R * ncy + 1;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int x = int(t % nx);
+    const long long rest = t / nx;
+    const int cy = int(rest % ncy), cz = int(rest / ncy);
+    const bool first_y = cy == 0, last_y = cy == ncy - 1, first_z = cz == 0, last_z = cz == ncz - 1;
+    T u[PC + 1][PC + 1]; // [az][ay]
+#pragma unroll
+    for (int az = 0; az <= PC; ++az)
+#pragma unroll
+      for (int ay = 0; ay <= PC; ++ay) u[az][ay] = in[x + (long long)nx * ((cy * (long long)PC + ay) + n_cy * (cz * (long long)PC + az))];
+    if (first_y && (flags_y & CF_LO_C)) {
+#pragma unroll
+      for (int az = 0; az <= PC; ++az) u[az][0] = T(0);
+    }
+    if (last_y && (flags_y & CF_HI_C)) {
+#pragma unroll
+      for (int az = 0; az <= PC; ++az) u[az][PC] = T(0);
+    }
+    if (first_z && (flags_z & CF_LO_C)) {
+#pragma unroll
+      for (int ay = 0; ay <= PC; ++ay) u[0][ay] = T(0);
+    }
+    if (last_z && (flags_z & CF_HI_C)) {
+#pragma unroll
+      for (int ay = 0; ay <= PC; ++ay) u[PC][ay] = T(0);
+    }
+    T *o = out + x + (long long)nx * (cy * (long long)R + n_fy * (cz * (long long)R));
+#pragma unroll
+    for (int jz = 0; jz <= R; ++jz) {
+      if (jz == R && !last_z) break; // the upper ends belong to the next cells
+      T tz[PC + 1];
+#pragma unroll
+      for (int ay = 0; ay <= PC; ++ay) {
+        T v = T(0);
+#pragma unroll
+        for (int az = 0; az <= PC; ++az) v += m.L[jz * (PC + 1) + az] * u[az][ay];
+        tz[ay] = v;
+      }
+      const bool con_z = (first_z && jz == 0 && (flags_z & CF_LO_F)) || (last_z && jz == R && (flags_z & CF_HI_F));
+#pragma unroll
+      for (int jy = 0; jy <= R; ++jy) {
+        if (jy == R && !last_y) break;
+        T v = T(0);
+#pragma unroll
+        for (int ay = 0; ay <= PC; ++ay) v += m.L[jy * (PC + 1) + ay] * tz[ay];
+        const bool constrained = con_z || (first_y && jy == 0 && (flags_y & CF_LO_F)) || (last_y && jy == R && (flags_y & CF_HI_F));
+        T *q = o + (long long)nx * (jy + n_fy * jz);
+        if (add) {
+          if (!constrained) *q += v;
+        } else *q = constrained ? T(0) : v;
+      }
+    }
+  }
+}
+
 // the transpose: coarse node a of cell c collects the fine values of its own cell and, for a = 0, of the interior of the cell before
 template <typename T, int PC, int R>
 __global__ void __launch_bounds__(256)
@@ -352,6 +418,31 @@ int launch_cell(bool prolongate, int pc, int R, T *out, const T *in, long long S
   return 1;
 }
 
+template <typename T>
+int launch_cell_yz(int pc, int R, T *out, const T *in, int nx, int ncy, int ncz, const double *L, int flags_y, int flags_z, int add, hipStream_t s)
+{
+  CellMat<T> m;
+  for (int i = 0; i < 9 * 5; ++i) m.L[i] = T(L[i]);
+  const long long total = (long long)nx * ncy * ncz;
+  const int blocks = int(std::min<long long>((total + 255) / 256, 1 << 20));
+#define STFEM_CELL_CASE(PC_, R_)                                                                                              \
+  if (pc == PC_ && R == R_) {                                                                                                 \
+    cell_prolongate_yz_kernel<T, PC_, R_><<<blocks, 256, 0, s>>>(out, in, nx, ncy, ncz, total, m, flags_y, flags_z, add);     \
+    TR_TRY(hipGetLastError());                                                                                                \
+    return STFEM_OK;                                                                                                          \
+  }
+  STFEM_CELL_CASE(1, 2) STFEM_CELL_CASE(2, 4) STFEM_CELL_CASE(3, 6) STFEM_CELL_CASE(4, 8) // h-transfers
+  STFEM_CELL_CASE(1, 3) STFEM_CELL_CASE(1, 4) STFEM_CELL_CASE(2, 3) STFEM_CELL_CASE(3, 4) // (p-transfers on the same cells)
+#undef STFEM_CELL_CASE
+  return 1;
+}
+
+// the y and z passes of the prolongation can run as one kernel: same coarse degree, refinement and embedding matrix along both
+static bool fuse_yz = [] {
+  const char *e = getenv("STFEM_TRANSFER_FUSE");
+  return !e || atoi(e) != 0;
+}();
+
 // out (dims of `to`) (+)= (B2 (x) B1 (x) B0) in; order: the axes in `order`, smallest intermediates first
 // cell: 0 = table-driven passes only (interpolation), 1 = prolongation, 2 = restriction in cell form along y and z
 template <typename T>
@@ -359,6 +450,20 @@ int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const 
 {
   int dims[3] = {B[0].n_in, B[1].n_in, B[2].n_in};
   const T *cur = static_cast<const T *>(in);
+  // (measured on the cfg-1 levels, two Q4 blocks: fp32 h 0.231 -> 0.153 ms, fp32 / fp64 p 0.208 -> 0.172 / 0.315 -> 0.253 ms; fp64 h with 81 weights in
+  // scalar registers 0.332 -> 0.340 ms, and below ~150 000 threads the one-cell-per-thread form has too few of them: both keep the three passes)
+  const long long yz_threads = (long long)B[0].n_out * t->ncc[1] * t->ncc[2];
+  const bool heavy = sizeof(T) == 8 && t->pc[1] == 4 && t->Rn[1] == 8;
+  if (cell == 1 && fuse_yz && order[0] == 0 && t->pc[1] == t->pc[2] && t->Rn[1] == t->Rn[2] && t->Rn[1] > t->pc[1] && yz_threads >= 150000 && !heavy &&
+      std::equal(t->L[1], t->L[1] + 9 * 5, t->L[2])) { // x pass (tables), then y and z in one kernel
+    dims[0] = B[0].n_out;
+    T *mid = static_cast<T *>(t->d_tmp[0]);
+    int st = launch_axis<T>(mid, cur, dims, 0, B[0], 0, s);
+    if (st != STFEM_OK) return st;
+    st = launch_cell_yz<T>(t->pc[1], t->Rn[1], static_cast<T *>(out), mid, dims[0], t->ncc[1], t->ncc[2], t->L[1], t->flags[1], t->flags[2], add, s);
+    if (st <= 0) return st;
+    dims[0] = B[0].n_in; // no instantiation: the three-pass form below
+  }
   for (int step = 0; step < 3; ++step) {
     const int ax = order[step];
     dims[ax] = B[ax].n_out;
