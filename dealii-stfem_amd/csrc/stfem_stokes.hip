@@ -476,6 +476,15 @@ __global__ __launch_bounds__(256, NO <= 2 ? 3 : 2) void stokes_grad_kernel(const
   double acc[NO][3];
 #pragma unroll
   for (int o = 0; o < NO; ++o) acc[o][0] = acc[o][1] = acc[o][2] = 0.0;
+  // the destination values this thread updates are fetched first: their latency runs beside the pressure gather's (the kernel is
+  // bound by dependent memory round trips, not by bytes: profiles/r3/stokes)
+  double old[NO <= 2 ? NO : 1][3];
+  if constexpr (NO <= 2) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) old[o][c] = (o < P.nout && P.out_u[o]) ? P.out_u[o][c * P.Nu + node] : 0.0;
+  }
   const int nc[3] = {P.ncx, P.ncy, P.ncz};
   const int idx[3] = {ix, iy, iz};
   if constexpr (!PDG) {
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(256, NO <= 2 ? 3 : 2) void stokes_grad_kernel(const
         g[0] = fma(wn[2][ez], a0, g[0]);
         g[1] = fma(wn[2][ez], a1, g[1]);
         g[2] = fma(wc[2][ez], a2, g[2]);
-        __builtin_amdgcn_sched_barrier(0); // nine loads in flight at a time
+        if constexpr (NO > 2) __builtin_amdgcn_sched_barrier(0); // (many destinations: nine loads in flight at a time keep the registers)
       }
       _Pragma("unroll") for (int o = 0; o < NO; ++o)
         if (o < P.nout)
@@ -564,7 +573,10 @@ _Pragma("unroll") for (int o = 0; o < NO; ++o)
   }
 _Pragma("unroll") for (int o = 0; o < NO; ++o)
     if (o < P.nout && P.out_u[o])
-      for (int c = 0; c < 3; ++c) P.out_u[o][c * P.Nu + node] -= acc[o][c];
+      for (int c = 0; c < 3; ++c) {
+        if constexpr (NO <= 2) P.out_u[o][c * P.Nu + node] = old[o][c] - acc[o][c];
+        else P.out_u[o][c * P.Nu + node] -= acc[o][c];
+      }
 }
 
 // out_p[o] (=, +=) sum_s wKp[o][s] sum_c B_c u_s,c: one thread per pressure DoF (FE_Q(1) node / FE_DGP(1) cell function)
