@@ -534,6 +534,16 @@ int stfem_internal_metric(stfem_ctx *c, const void **metric, void *stream)
   return rc;
 }
 
+int stfem_internal_set_gradient(stfem_ctx *c, const double *p, const double (*w)[2][3][2], double scale)
+{
+  if (!c) return STFEM_ERR_INVALID_ARGUMENT;
+  c->grad_p = p;
+  c->grad_scale = scale;
+  c->grad_applied = false;
+  if (p && w) std::memcpy(c->grad_w, w, sizeof(c->grad_w));
+  return STFEM_OK;
+}
+
 // a(j,i), b(j,i): effective nbo x nbi matrices (row-major)
 template <class PR>
 static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<double> &a,
@@ -565,6 +575,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
     prm.vol = real(1); // detJ and the weights live in the metric
   }
   prm.experiment = c->env_exp;
+  prm.gp = nullptr;
   // Systems with more blocks than one launch takes are cut into panels (dst += for the later column panels).  On the
   // pencil path a launch needs two cells per wave - Q4 with seven or eight blocks has one - so those systems
   // are cut into equal panels of a size the pencil sweep has (Q4 x 8 blocks: 2 x 2 panels of four).
@@ -623,6 +634,15 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
         pp.yh = static_cast<real *>(c->d_halo);
         pp.zh = pp.yh + nyh;
         pp.add = (add || !first) ? 1 : 0;
+        prm.gp = nullptr;
+        if constexpr (sizeof(real) == 8) { // the Stokes gradient term rides in this launch (three FE_Q(2) blocks, dst = ..., no coefficient tables)
+          if (c->grad_p && c->p == 2 && tj == 3 && ti == 3 && !pp.add && last_panel && !prm.coef_lap && !prm.coef_mass) {
+            prm.gp = c->grad_p;
+            prm.gscale = c->grad_scale;
+            std::memcpy(prm.gw, c->grad_w, sizeof(prm.gw));
+            c->grad_applied = true;
+          }
+        }
         if (!c->d_work) {
           if (hipMalloc(&c->d_work, 8 * 32 * sizeof(int)) != hipSuccess) return STFEM_ERR_OUT_OF_MEMORY;
           HIP_TRY(hipMemsetAsync(c->d_work, 0, 8 * 32 * sizeof(int), st));

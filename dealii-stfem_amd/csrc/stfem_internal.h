@@ -38,7 +38,14 @@ struct stfem_ctx {
   void *d_metric = nullptr;
   bool metric_valid = false;
   int metric_flags = -1; // which coefficients are baked into d_metric (bit0 laplace, bit1 mass)
+  // csrc/stfem_stokes.hip: the next store-mode sweep of three FE_Q(2) blocks adds - grad_scale B^T p (SweepParams::gp); set and
+  // cleared around one stfem_st_vmult by stfem_internal_set_gradient, grad_applied tells whether a launch took it
+  const double *grad_p = nullptr;
+  double grad_w[3][2][3][2];
+  double grad_scale = 0.0;
+  bool grad_applied = false;
 };
+int stfem_internal_set_gradient(stfem_ctx *c, const double *p, const double (*w)[2][3][2], double scale);
 
 struct stfem_vec {
   stfem_ctx *ctx = nullptr;

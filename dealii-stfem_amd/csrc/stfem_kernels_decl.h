@@ -28,6 +28,13 @@ struct SweepParams {
   // per-quadrature-point metric records [cell][qz][qy][qx][8] = (Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,Mq,pad)
   real_t eo_S[EO_N], eo_Dq[EO_N], eo_DqT[EO_N];
   const real_t *metric;
+  // Stokes (csrc/stfem_stokes.hip, Kronecker path): with the three velocity components as the blocks of a FE_Q(2) sweep the kernel
+  // can add the pressure gradient term - gscale * B^T p to what it stores (no second kernel reading and writing the velocity
+  // again): gp = the FE_Q(1) pressure on the (ncx + 1)(ncy + 1)(ncz + 1) cell vertices (nullptr: off), gw[d][f][a][j] = the 1D
+  // integrals of direction d between velocity node a and pressure vertex j, f = 0: derivative form (C), f = 1: value form (h_d N)
+  const real_t *gp;
+  real_t gw[3][2][3][2];
+  real_t gscale;
 };
 
 // Decomposition used by the "tile" variant: a workgroup owns a tile of cw x rows cells in x-y and

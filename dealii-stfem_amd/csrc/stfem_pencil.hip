@@ -119,9 +119,14 @@ template <int P, int NBM, int TY> struct PencilGeom {
   // systems of four and more blocks keep the temporal weights in an LDS table [output block][input block][K, M]
   static constexpr bool WLDS = NBM >= 4;
   static constexpr int WTAB = WLDS ? 2 * NBM * NBM : 0;
+  // Q2 with three blocks (the velocity components of the Stokes operator): a wave-private tile of the pressure values around the
+  // wave's cells of one layer, [2 z-vertices][TY + 1 y-vertices][CPW + 2 x-vertices] (SweepParams::gp)
+  static constexpr bool HAS_GRAD = P == 2 && NBM == 3 && sizeof(real_t) == 8;
+  static constexpr int GPT_WAVE = HAS_GRAD ? 2 * (TY + 1) * (CPW + 2) : 0;
   // transpose slabs, mailboxes, hand-over counters + tile number, weight table (dynamic LDS: above the 64 KB static limit for Q4)
   static constexpr size_t LDS_BYTES =
-    sizeof(real_t) * (size_t(WY) * PencilCore<P, NBM>::LDS_PER_WAVE + size_t(WY - 1) * 2 * MAIL + WTAB) + sizeof(int) * (2 * WY + 4);
+    sizeof(real_t) * (size_t(WY) * PencilCore<P, NBM>::LDS_PER_WAVE + size_t(WY - 1) * 2 * MAIL + WTAB + size_t(WY) * GPT_WAVE) +
+    sizeof(int) * (2 * WY + 4);
 };
 
 
@@ -135,7 +140,7 @@ enum : unsigned {
   LF_XCON = 128 // its column is a Dirichlet column (x faces)
 };
 
-template <int P, int NBM, int TY, bool ADD, bool COEF>
+template <int P, int NBM, int TY, bool ADD, bool COEF, bool GRAD = false>
 __global__ __launch_bounds__(64 * PENCIL_WY, 2)
 void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
 {
@@ -159,6 +164,7 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
   volatile int *s_tile = flags + 2 * WY;
   // weight table of the systems with four and more blocks (read-only after the first barrier of the tile loop)
   real_t *wtab = const_cast<real_t *>(reinterpret_cast<volatile real_t *>(flags + 2 * WY + 4));
+  [[maybe_unused]] real_t *gpt = wtab + PG::WTAB + wave * PG::GPT_WAVE; // GRAD: this wave's pressure tile
   if constexpr (PG::WLDS) {
     for (int e = threadIdx.x; e < NBM * NBM; e += PG::NT) {
       const int j = e / NBM, q = e % NBM;
@@ -234,6 +240,36 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
          (st ? LF_ST : 0) | (xcon ? LF_XCON : 0);
   }
   const int cx = cx0 + ((lf & (LF_IN | LF_OUT)) ? c : 1);
+
+  // GRAD: this lane's part of - gscale B^T p.  x faces are complete when a row leaves the core (the x = P value of a cell was added to
+  // the next cell's x = 0 slot in the middle phase), so the lane adds what BOTH x-cells of its node contribute: assembled weights
+  // against the pressure vertices p0x .. p0x + 2; in y and z the cell's own contribution, which the carries / mailboxes / halo slabs
+  // complete like the rest of the cell's result.
+  [[maybe_unused]] real_t gwx[3] = {real_t(0), real_t(0), real_t(0)}, gWy[N][2], gWz[N][2];
+  [[maybe_unused]] int gxv = 0;
+  if constexpr (GRAD) {
+    // (every table entry is picked with selects on compile-time indices: a lane-indexed read of the kernel arguments would be a
+    // vector-memory load from the argument segment)
+    const int comp = blk < 3 ? blk : 0;
+    auto W = [&](int d, int a, int j) { return comp == d ? prm.gw[d][0][a][j] : prm.gw[d][1][a][j]; }; // derivative form along the component's own axis
+    const int cxg = cx0 + c;
+    const bool lo = cxg > 0;
+    const real_t mid0 = W(0, 1, 0), mid1 = W(0, 1, 1);
+    const real_t v0 = lo ? W(0, 2, 0) : real_t(0), v1 = (lo ? W(0, 2, 1) : real_t(0)) + W(0, 0, 0), v2 = W(0, 0, 1);
+    const real_t e0 = W(0, 2, 0), e1 = W(0, 2, 1); // the x = P column: stored at the mesh boundary only
+    gwx[0] = (i == 1 ? mid0 : (i == 0 ? v0 : e0)) * prm.gscale;
+    gwx[1] = (i == 1 ? mid1 : (i == 0 ? v1 : e1)) * prm.gscale;
+    gwx[2] = (i == 0 ? v2 : real_t(0)) * prm.gscale;
+    const int p0x = i == 0 ? cxg - 1 : cxg;
+    gxv = min(max(p0x - cx0, 0), CPW - 1); // first of the lane's three x-vertices within the tile (halo-slot lanes: anything in range)
+    STFEM_UNROLL
+    for (int a = 0; a < N; ++a)
+      STFEM_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      gWy[a][j] = W(1, a, j);
+      gWz[a][j] = W(2, a, j);
+    }
+  }
 
   // eigenvalue of this lane's z-mode in the middle phase of the core
   real_t lzk = prm.fd_lz[0];
@@ -343,6 +379,14 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
 
   for (int layer = 0; layer < nlay; ++layer) {
     const int cz = cz0 + layer;
+    if constexpr (GRAD) { // the pressure values around this wave's cells of the layer (LDS operations of a wave execute in order)
+      constexpr int XV = CPW + 2, YV = TY + 1;
+      for (int e = lane; e < 2 * YV * XV; e += 64) {
+        const int jz = e / (YV * XV), rem = e - jz * (YV * XV), yv = rem / XV, xv = rem - yv * XV;
+        const int xg = min(max(cx0 + xv, 0), prm.ncx), yg = min(cy0 + yv, prm.ncy);
+        gpt[e] = prm.gp[xg + int64_t(prm.ncx + 1) * (yg + int64_t(prm.ncy + 1) * (cz + jz))];
+      }
+    }
     const bool last_layer = layer == nlay - 1;
     const bool z_lo = (prm.dmask & 16) && cz == 0, z_hi = (prm.dmask & 32) && cz == prm.ncz - 1;
     const bool masked = xy_boundary || z_lo || z_hi;
@@ -374,6 +418,17 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
         return (lf & LF_XCON) || (y == 0 && y_lo) || (y == P && y_hi) || (z == 0 && z_lo) || (z == P && z_hi);
       };
       PTL(0);
+      [[maybe_unused]] real_t ga[2][2]; // GRAD: the x-contracted pressure values of the cell's four (y, z) vertex lines
+      if constexpr (GRAD) {
+        constexpr int XV = CPW + 2, YV = TY + 1;
+        STFEM_UNROLL
+        for (int jz = 0; jz < 2; ++jz)
+          STFEM_UNROLL
+        for (int jy = 0; jy < 2; ++jy) {
+          const real_t *q = gpt + (jz * YV + cyl + jy) * XV + gxv;
+          ga[jy][jz] = gwx[0] * q[0] + gwx[1] * q[1] + gwx[2] * q[2];
+        }
+      }
       if (masked) {
         STFEM_UNROLL
         for (int y = 0; y < N; ++y)
@@ -448,6 +503,11 @@ void st_sweep_pencil(const SweepParams prm, const PencilPlan pp)
 #ifdef STFEM_PENCIL_TOUCH
         touch_row(y);
 #endif
+        if constexpr (GRAD) { // this cell's gradient term at the row's nodes (before the constrained DoFs are zeroed)
+          const real_t b0 = gWy[y][0] * ga[0][0] + gWy[y][1] * ga[1][0], b1 = gWy[y][0] * ga[0][1] + gWy[y][1] * ga[1][1];
+          STFEM_UNROLL
+          for (int z = 0; z < N; ++z) r[z] += gWz[z][0] * b0 + gWz[z][1] * b1;
+        }
         if (masked) {
           STFEM_UNROLL
           for (int z = 0; z < N; ++z)
@@ -677,7 +737,21 @@ template <int P, int NBM, int TY> int launch_pencil_ty(const SweepParams &prm, c
     }                                                                                                             \
     hipLaunchKernelGGL((st_sweep_pencil<P, NBM, TY, AA, CC>), dim3(grid), dim3(PG::NT), PG::LDS_BYTES, st, prm, pp); \
   } while (0)
-  if (pp.add && coef) STFEM_LAUNCH(true, true);
+  if constexpr (PG::HAS_GRAD) {
+    if (prm.gp) { // (the caller sets gp only for dst = ..., no coefficients: csrc/stfem_capi.hip)
+      if (pp.add || coef) return -2;
+      static bool lds_set = false;
+      if (!lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&st_sweep_pencil<P, NBM, TY, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(PG::LDS_BYTES)) != hipSuccess)
+          return -3;
+        lds_set = true;
+      }
+      hipLaunchKernelGGL((st_sweep_pencil<P, NBM, TY, false, false, true>), dim3(grid), dim3(PG::NT), PG::LDS_BYTES, st, prm, pp);
+    }
+  }
+  if (PG::HAS_GRAD && prm.gp) {
+  } else if (pp.add && coef) STFEM_LAUNCH(true, true);
   else if (pp.add) STFEM_LAUNCH(true, false);
   else if (coef) STFEM_LAUNCH(false, true);
   else STFEM_LAUNCH(false, false);

@@ -1251,6 +1251,7 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
   // (the fork point is here, before the sweep; the side stream's commands are enqueued after the sweep's so that the sweep's
   // persistent workgroups - exactly the resident number - are placed first and the divergence kernel fills what is left)
   if (forked) STOKES_TRY(hipEventRecord(c->ev_fork, st));
+  bool grad_fused = false;
   // ---- 1. velocity blocks: out_u[o] (=, +=) sum_q (nu wKu K + wM M) u_q, component by component as scalar FE_Q(2) systems
   // (one launch with the three components as blocks when there is a single source and destination)
   for (int pass = 0; pass < 2; ++pass) { // destinations that are overwritten, then those that are accumulated into
@@ -1275,7 +1276,25 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
       stfem_vec *vd = nullptr, *vs = nullptr;
       int rc = stfem_vector_wrap(c->scalar, nbo, dptr.data(), &vd);
       if (rc == STFEM_OK) rc = stfem_vector_wrap(c->scalar, nbi, sptr.data(), &vs);
+      // one time dof, FE_Q(1) pressure, destination overwritten: the sweep adds - wKu B^T p to what it stores (SweepParams::gp) and
+      // the gradient kernel below is not needed (it read and wrote the whole velocity destination again)
+      static const bool unfused = [] { const char *e = getenv("STFEM_STOKES_GRAD_KERNEL"); return e && atoi(e) != 0; }();
+      const bool fuse = ncomp_blocks == 3 && pass == 0 && !c->pspace && ps[0] && wKu[rows[0]][0] != 0.0 && !unfused;
+      if (fuse && rc == STFEM_OK) {
+        double w[3][2][3][2];
+        for (int d = 0; d < 3; ++d)
+          for (int a3 = 0; a3 < 3; ++a3)
+            for (int j = 0; j < 2; ++j) {
+              w[d][0][a3][j] = c->coupling.C[a3][j];
+              w[d][1][a3][j] = c->coupling.h[d] * c->coupling.N[a3][j];
+            }
+        rc = stfem_internal_set_gradient(c->scalar, ps[0], w, -wKu[rows[0]][0]);
+      }
       if (rc == STFEM_OK) rc = stfem_st_vmult(c->scalar, nbo, nbi, a.data(), b.data(), 0, pass, vd, vs, st);
+      if (fuse) {
+        if (rc == STFEM_OK && c->scalar->grad_applied) grad_fused = true;
+        (void)stfem_internal_set_gradient(c->scalar, nullptr, nullptr, 0.0);
+      }
       if (vd) stfem_vector_destroy(vd);
       if (vs) stfem_vector_destroy(vs);
       if (rc != STFEM_OK) {
@@ -1290,7 +1309,7 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
     STOKES_TRY(hipEventRecord(c->ev_join, c->side));
   }
   // ---- 3. out_u -= sum_q wKu B^T p_q
-  if (k_u) {
+  if (k_u && !grad_fused) {
     if (shape == 0) STOKES_COUPLING_LAUNCH(grad, 1, 1, gu, k);
     else if (shape == 1) STOKES_COUPLING_LAUNCH(grad, 2, 2, gu, k);
     else if (shape == 2) STOKES_COUPLING_LAUNCH(grad, MAXSRC, 4, gu, k);
