@@ -1,6 +1,12 @@
-// Stokes two-field cell operator on MI355X (BASELINE configs[4]).
+// Stokes two-field operator on MI355X (BASELINE configs[4]).
 //
-// Replaces, for the cell loop (LoopType::Cell: no weak boundary ids, delta0 = 0):
+// Two implementations of the cell loop.  Axis-aligned uniform meshes: the Kronecker form further down ("axis-aligned uniform
+// meshes") - the velocity components as the blocks of the scalar FE_Q(2) pencil sweep (csrc/stfem_pencil.hip), for one time dof
+// with the pressure gradient term folded into that sweep, and the divergence as a marching gather kernel.  General meshes: the
+// cell kernel described next.  On top of either: the weak (Nitsche) boundary faces (stokes_boundary_kernel) and the helpers of the
+// pressure space the solver around the operator needs (end of the file).
+//
+// The cell kernel replaces, for the cell loop (LoopType::Cell: no weak boundary ids, delta0 = 0):
 //   StokesMatrixFreeOperator::do_cell_integral_range / do_cell_integral_local
 //       (reference include/operators.h:1501-1575, OperatorMode::none):
 //       pressure.submit_value(div u); velocity.submit_gradient(nu grad u - p I)
