@@ -330,8 +330,8 @@ def test_stokes_dg_pressure_vs_oracle(nc, distort, mask, weak, stfem):
             assert rel(dst[j].download(), ref[j]) < TOL, (ns, r, j)
 
 
-@pytest.mark.parametrize("world,dg", [(2, False), (3, False), (2, True)])
-def test_stokes_on_z_slabs_equals_whole_mesh(world, dg, stfem):
+@pytest.mark.parametrize("world,dg,r", [(2, False, 2), (3, False, 2), (2, True, 2), (2, False, 1), (3, False, 1)])
+def test_stokes_on_z_slabs_equals_whole_mesh(world, dg, r, stfem):
     """The Stokes operator shards like the scalar one (BASELINE configs[4] is an 8-GPU configuration): on a z-slab whose interface
     faces are taken out of the Dirichlet mask the kernels leave PARTIAL sums in the interface planes of the velocity components and of
     the FE_Q(1) pressure (the gather-form coupling kernels count the slab's own cells only; FE_DGP pressure DoFs are cell-local); adding
@@ -340,8 +340,9 @@ def test_stokes_on_z_slabs_equals_whole_mesh(world, dg, stfem):
     nc, nu_ = (3, 2, 6), 0.8
     weak = [0]  # a weak (Nitsche) x- face: boundary cells of every slab
     mask = 63 & ~1
-    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, 2, 0.1, 1)
-    nt = 2
+    # (r = 1: one time dof - the pressure gradient rides in the velocity sweep; r = 2: the separate gradient kernel)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 0.1, 1)
+    nt = r
     rng = np.random.default_rng(8)
     ndu = [2 * c + 1 for c in nc]
     ndp = [c + 1 for c in nc]
