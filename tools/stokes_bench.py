@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 stfem = importlib.import_module("dealii-stfem_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 r = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-op = stfem.StokesMatrixFreeOperator((N, N, N), viscosity=1.0)
+dg = len(sys.argv) > 3 and sys.argv[3] == "dg"  # FE_DGP(1) pressure
+op = stfem.StokesMatrixFreeOperator((N, N, N), viscosity=1.0, dg_pressure=dg)
 Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, r, 1.0 / 64, 1)
 nt = r
 rng = np.random.default_rng(0)
@@ -35,5 +36,5 @@ t1 = time.perf_counter()
 dl0 = time.perf_counter(); dst[0].download(); dl = time.perf_counter() - dl0
 ms = ((t1 - t0) - dl) / reps * 1e3
 dofs = nt * (3 * op.n_velocity + op.n_pressure)
-print(f"Stokes Q2/Q1 x cG({r}), {N}^3 cells, {dofs} space-time DoFs: {ms:.3f} ms per vmult, "
+print(f"Stokes Q2/{'P1disc' if dg else 'Q1'} x cG({r}), {N}^3 cells, {dofs} space-time DoFs: {ms:.3f} ms per vmult, "
       f"{dofs / ms * 1e3:.3e} DoF/s, {16 * dofs / ms * 1e-6:.1f} GB/s algorithmic")
