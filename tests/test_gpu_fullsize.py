@@ -193,3 +193,49 @@ def test_cfg2_full_mesh_properties(stfem):
     out = stfem.BlockVector(free, 2)
     stfem.SystemMatrix(free, I2, Z2).vmult(out, ones)
     assert np.abs(out.download()).max() < 1e-9
+
+
+@pytest.mark.parametrize("dg", [False, True])
+def test_cfg4_stokes_full_size_properties(dg, stfem):
+    """BASELINE configs[4] (Stokes, FE_Q(2)^3 x FE_Q(1) or FE_DGP(1)) at bench size: 64^3 cells, 6.4 M velocity DoFs.  Checked:
+    the Kronecker path (pencil sweep + coupling kernels) against the cell kernel on the same mesh handed over as a vertex array
+    (two independent kernels and algorithms), linearity, constrained velocity rows exactly zero, and the block structure
+    [[A, G], [-G^T, 0]] of StokesMatrixFreeOperator::vmult (operators.h:1501-1575): A symmetric, q.(B u) = -u.(G q), no
+    pressure-pressure block."""
+    nc, nu = (64, 64, 64), 0.7
+    fast = stfem.StokesMatrixFreeOperator(nc, dirichlet_mask=63, viscosity=nu, dg_pressure=dg)
+    cell = stfem.StokesMatrixFreeOperator(nc, vertices=stfem.mesh_vertices(nc, (0, 0, 0), (1, 1, 1)), dirichlet_mask=63, viscosity=nu,
+                                          dg_pressure=dg)
+    n_u, n_p, nd = fast.n_velocity, fast.n_pressure, 129
+    assert n_u == nd ** 3 and n_p == (4 * 64 ** 3 if dg else 65 ** 3) and cell.n_pressure == n_p
+
+    def field(seed):  # velocity with zero boundary rows, pressure
+        g = np.random.default_rng(seed)
+        u = g.uniform(-1, 1, (3, nd, nd, nd))
+        u[:, 0] = 0; u[:, -1] = 0; u[:, :, 0] = 0; u[:, :, -1] = 0; u[:, :, :, 0] = 0; u[:, :, :, -1] = 0
+        return u.reshape(-1), g.uniform(-1, 1, n_p)
+
+    def apply(op, u, p):
+        du, dp = op.initialize_dof_vector(0, np.full(3 * n_u, 3.0)), op.initialize_dof_vector(1, np.full(n_p, -2.0))
+        op.vmult(du, dp, op.initialize_dof_vector(0, u), op.initialize_dof_vector(1, p))
+        return du.download(), dp.download()
+
+    (U, P), (V, Q) = field(5), field(6)
+    ku, kp = apply(fast, U, P)
+    cu, cp = apply(cell, U, P)
+    assert rel(ku, cu) < 1e-12 and rel(kp, cp) < 1e-12
+    del cu, cp, cell
+    g = ku.reshape(3, nd, nd, nd)
+    for sl in (g[:, 0], g[:, -1], g[:, :, 0], g[:, :, -1], g[:, :, :, 0], g[:, :, :, -1]):
+        assert np.all(sl == 0.0)
+    lu, lp = apply(fast, V, Q)
+    su, sp = apply(fast, 0.5 * U - 3.0 * V, 0.5 * P - 3.0 * Q)
+    assert rel(su, 0.5 * ku - 3.0 * lu) < 1e-13 and rel(sp, 0.5 * kp - 3.0 * lp) < 1e-13
+    del su, sp, ku, kp, lu, lp
+    zero_u, zero_p = np.zeros(3 * n_u), np.zeros(n_p)
+    au, bu = apply(fast, U, zero_p)      # A U, B U
+    av, _ = apply(fast, V, zero_p)
+    assert abs(np.vdot(V, au) - np.vdot(U, av)) < 1e-12 * abs(np.vdot(V, au)) and np.vdot(U, au) > 0
+    gq, zq = apply(fast, zero_u, Q)      # G Q, 0
+    assert np.all(zq == 0.0)
+    assert abs(np.vdot(Q, bu) + np.vdot(U, gq)) < 1e-12 * np.linalg.norm(Q) * np.linalg.norm(bu)
