@@ -7,6 +7,8 @@
 #include "stokes.h"
 #include "time_integrators.h"
 
+#include <chrono>
+
 namespace stfem {
 
 // The scalar spaces behind the two variables: a velocity component is a FE_Q(2) function (with the velocity's strong constraints),
@@ -473,7 +475,11 @@ public:
     }
     for (unsigned i = 0; i < x.n_blocks(); ++i) // extrapolate (time_integrators.h:184-194): every time dof starts from the previous solution
       axpby(1.0, prev.view(slice.decompose(i)[1]), 0.0, x.view(i));
+    (void)dot(rhs.view(0), rhs.view(0)); // (synchronises: the clock below sees the Krylov solve alone)
+    const auto t0 = std::chrono::steady_clock::now();
     solver.solve(matrix, x, rhs, preconditioner);
+    (void)dot(x.view(0), x.view(0));
+    solver_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (zero_mean) {
       if (!weights.handle()) { // mean(p) = weights . p / |Omega|, p -= mean * ones (VectorTools::compute_mean_value / add_constant)
         weights.reinit(sp.q1, 1);
@@ -490,8 +496,10 @@ public:
     }
   }
   unsigned last_step() const { return solver.last_step(); }
+  double solver_seconds() const { return solver_seconds_; } // wall time of the FGMRES solves so far (without the right-hand sides)
 
 private:
+  double solver_seconds_ = 0.0;
   TimeStepType type;
   unsigned time_degree;
   std::vector<double> quad_time;
