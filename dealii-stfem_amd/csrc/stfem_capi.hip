@@ -31,7 +31,7 @@ struct Prec64 {
   static int geometry(int p, int nbm, int general, Plan &pl) { return f64::tile_geometry(p, nbm, general, pl); }
   static int occupancy(int p, int nbm, int general)
   {
-    static int cache[5][stfem::MAX_BLOCKS + 1][2] = {}; // 0 = not asked yet (one device type per process)
+    static int cache[6][stfem::MAX_BLOCKS + 1][2] = {}; // 0 = not asked yet (one device type per process)
     int &v = cache[p][nbm][general];
     if (v == 0) v = std::max(1, f64::tile_occupancy(p, nbm, general)) + 100;
     return v - 100;
@@ -59,7 +59,7 @@ struct Prec32 {
   static int geometry(int p, int nbm, int general, Plan &pl) { return f32::tile_geometry(p, nbm, general, pl); }
   static int occupancy(int p, int nbm, int general)
   {
-    static int cache[5][stfem::MAX_BLOCKS + 1][2] = {};
+    static int cache[6][stfem::MAX_BLOCKS + 1][2] = {};
     int &v = cache[p][nbm][general];
     if (v == 0) v = std::max(1, f32::tile_occupancy(p, nbm, general)) + 100;
     return v - 100;
@@ -120,7 +120,7 @@ int stfem_ctx_create(const stfem_mesh_desc *mesh, const stfem_space_desc *space,
 {
   if (!mesh || !space || !out) return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  if (space->degree < 1 || space->degree > 4) return STFEM_ERR_UNSUPPORTED;
+  if (space->degree < 1 || space->degree > 5) return STFEM_ERR_UNSUPPORTED;
   if (space->n_q_points_1d != space->degree + 1 || space->n_components != 1)
     return STFEM_ERR_UNSUPPORTED;
   if (space->precision != 0 && space->precision != 1) return STFEM_ERR_UNSUPPORTED;
@@ -580,7 +580,7 @@ static int apply_tiled_t(stfem_ctx *c, int nbo, int nbi, const std::vector<doubl
   // pencil path a launch needs two cells per wave - Q4 with seven or eight blocks has one - so those systems
   // are cut into equal panels of a size the pencil sweep has (Q4 x 8 blocks: 2 x 2 panels of four).
   int panel = MAX_BLOCKS;
-  if (c->variant == 0 && !general) {
+  if (c->variant == 0 && !general && c->p <= 4) { // (FE_Q(5) has no pencil sweep: the tile sweep takes up to MAX_BLOCKS blocks)
     const int need = std::min(MAX_BLOCKS, std::max(nbo, nbi));
     typename PR::PPlan probe;
     std::memset(&probe, 0, sizeof(probe));

@@ -7,7 +7,7 @@
 
 namespace stfem {
 constexpr int MAX_BLOCKS = 8; // temporal blocks handled by one launch (larger systems are tiled)
-constexpr int EO_N = 16;      // >= eo_size(5)
+constexpr int EO_N = 20;      // >= eo_size(6) = 18 (FE_Q(5))
 
 } // namespace stfem
 

@@ -792,7 +792,7 @@ template <int P, int NBM, int WV> int tile_occupancy_w(bool general)
 template <int P, int NBM> int tile_occupancy_t(bool general)
 {
 #ifdef STFEM_F32
-  return tile_occupancy_w<P, NBM, 4>(general);
+  return tile_occupancy_w<P, NBM, (P >= 5 ? 2 : 4)>(general); // (FE_Q(5): the 128-register variants spill)
 #else
   return tile_occupancy_w<P, NBM, 2>(general); // (the 168-VGPR, three-per-CU variants spill for some (P, NBM))
 #endif
@@ -802,7 +802,7 @@ template <int P, int NBM> int launch_tile_t(const SweepParams &prm, const TilePl
 {
 #ifdef STFEM_F32
   // half the registers and half the LDS per workgroup: twice the waves per SIMD
-  return launch_tile_w<P, NBM, 4>(prm, tp, st);
+  return launch_tile_w<P, NBM, (P >= 5 ? 2 : 4)>(prm, tp, st);
 #else
   return launch_tile_w<P, NBM, 2>(prm, tp, st);
 #endif
@@ -888,7 +888,7 @@ int launch_build_metric(int p, const int nc[3], const double *d_vertices, const 
 
 int tile_geometry(int p, int nbm, int general, TilePlan &plan)
 {
-  if (p < 1 || p > 4) return -2;
+  if (p < 1 || p > 5) return -2;
   nbm = round_nbm(nbm);
   const int n = p + 1;
   const int cb = 64 / n;
@@ -905,7 +905,7 @@ int tile_geometry(int p, int nbm, int general, TilePlan &plan)
 #endif // !STFEM_TILE_P
 
 // The kernel templates are compiled once per degree (make builds this file with
-// -DSTFEM_TILE_P=1..4 in parallel); the translation unit without STFEM_TILE_P holds the common
+// -DSTFEM_TILE_P=1..5 in parallel); the translation unit without STFEM_TILE_P holds the common
 // host code and the dispatcher.
 #if STFEM_TILE_P
 #define STFEM_PASTE2(a, b) a##b
@@ -941,6 +941,7 @@ int tile_occupancy_p1(int, int);
 int tile_occupancy_p2(int, int);
 int tile_occupancy_p3(int, int);
 int tile_occupancy_p4(int, int);
+int tile_occupancy_p5(int, int);
 int tile_occupancy(int p, int nbm, int general)
 {
   switch (p) {
@@ -948,6 +949,7 @@ int tile_occupancy(int p, int nbm, int general)
     case 2: return tile_occupancy_p2(nbm, general);
     case 3: return tile_occupancy_p3(nbm, general);
     case 4: return tile_occupancy_p4(nbm, general);
+    case 5: return tile_occupancy_p5(nbm, general);
     default: return 0;
   }
 }
@@ -955,6 +957,7 @@ int launch_cart_tile_p1(const SweepParams &, const TilePlan &, hipStream_t);
 int launch_cart_tile_p2(const SweepParams &, const TilePlan &, hipStream_t);
 int launch_cart_tile_p3(const SweepParams &, const TilePlan &, hipStream_t);
 int launch_cart_tile_p4(const SweepParams &, const TilePlan &, hipStream_t);
+int launch_cart_tile_p5(const SweepParams &, const TilePlan &, hipStream_t);
 
 int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *stream)
 {
@@ -964,6 +967,7 @@ int launch_cart_tile(int p, const SweepParams &prm, const TilePlan &plan, void *
     case 2: return launch_cart_tile_p2(prm, plan, st);
     case 3: return launch_cart_tile_p3(prm, plan, st);
     case 4: return launch_cart_tile_p4(prm, plan, st);
+    case 5: return launch_cart_tile_p5(prm, plan, st); // FE_Q(5): this path only (the pencil sweep needs more registers than a wave has)
     default: return -2;
   }
 }

@@ -339,7 +339,9 @@ struct stfem_transfer {
   stfem_ctx *fine = nullptr, *coarse = nullptr;
   Band P[3], R[3], I[3]; // per direction: prolongation rows, its transpose, nodal interpolation (all with the constraints)
   // cell form of P / R along y and z: local embedding matrix, coarse degree, fine nodes per coarse cell, coarse cells, constrained ends
-  double L[3][9 * 5];
+  // (up to FE_Q(5) on both levels with two fine cells per coarse one: 11 x 6 entries; the cell kernels are instantiated up to
+  // FE_Q(4): 9 x 5, larger blocks take the table-driven passes)
+  double L[3][11 * 6] = {};
   bool cell_restrict_z = true;
   bool cell_form = true; // STFEM_TRANSFER_TABLES=1: table-driven passes along every axis (for comparison)
   int pc[3] = {0, 0, 0}, Rn[3] = {0, 0, 0}, ncc[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
@@ -455,7 +457,7 @@ int apply3(stfem_transfer *t, const Band B[3], void *out, const void *in, const 
   const long long yz_threads = (long long)B[0].n_out * t->ncc[1] * t->ncc[2];
   const bool heavy = sizeof(T) == 8 && t->pc[1] == 4 && t->Rn[1] == 8;
   if (cell == 1 && fuse_yz && order[0] == 0 && t->pc[1] == t->pc[2] && t->Rn[1] == t->Rn[2] && t->Rn[1] > t->pc[1] && yz_threads >= 150000 && !heavy &&
-      std::equal(t->L[1], t->L[1] + 9 * 5, t->L[2])) { // x pass (tables), then y and z in one kernel
+      std::equal(t->L[1], t->L[1] + 11 * 6, t->L[2])) { // x pass (tables), then y and z in one kernel
     dims[0] = B[0].n_out;
     T *mid = static_cast<T *>(t->d_tmp[0]);
     int st = launch_axis<T>(mid, cur, dims, 0, B[0], 0, s);

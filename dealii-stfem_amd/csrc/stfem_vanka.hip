@@ -774,7 +774,7 @@ int stfem_vanka_create_partitioned(stfem_ctx *c, int nb, const double *Alpha, co
     return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
-  if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 4 temporal blocks
+  if (m > VK_MAX_ROWS || p > 4) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 4 temporal blocks; the apply kernels are instantiated up to FE_Q(4)
   VK_TRY(hipSetDevice(c->device));
   stfem_vanka *v = new (std::nothrow) stfem_vanka;
   if (!v) return STFEM_ERR_OUT_OF_MEMORY;

@@ -194,7 +194,7 @@ def golden_tables(golden_dir):
 
 # the first run of the golden: tests/json/tf01.json (dG(k), two steps at once, k = 1..3);
 # the second: tests/json/tf02.json (cG(k), k = 2..4)
-CASES = [("DG", 1, 0), ("DG", 2, 1), ("CG", 2, 3), ("CG", 3, 4)]
+CASES = [("DG", 1, 0), ("DG", 2, 1), ("CG", 2, 3), ("CG", 3, 4), ("CG", 4, 5)]  # (the last one: FE_Q(5) x cG(4))
 
 
 @pytest.mark.parametrize("kind,k,table", CASES)
@@ -208,10 +208,12 @@ def test_heat_convergence_rows_of_tp01(oracle_mod, golden_dir, kind, k, table):
     for ref, (cells, _, g8, g2, gh) in zip((2, 3), rows[:2]):  # the first two refinements
         assert cells == 4 ** ref
         l8, l2, h1 = convergence_row(o, ttype, k, ref)
-        # to the printed digits (%.5e: half a unit of the sixth digit, plus the solver tolerance)
+        # to the printed digits (%.5e: half a unit of the sixth digit, plus the solver tolerance: the reference stops its FGMRES at
+        # a residual of 1e-12 (time_integrators.h:50-56), the slab systems here are solved directly - that shows in the sixth
+        # digit of the FE_Q(5) rows only, whose errors are below 1e-6)
         for name, got, gold in (("L2-L2", l2, g2), ("L2-H1", h1, gh), ("Linf", l8, g8)):
             ulp = 10.0 ** (np.floor(np.log10(gold)) - 5)
-            assert abs(got - gold) <= 0.51 * ulp + 1e-9 * gold, (kind, k, ref, name, got, gold)
+            assert abs(got - gold) <= 0.51 * ulp + 1e-9 * gold + 2e-12, (kind, k, ref, name, got, gold)
 
 
 @pytest.mark.parametrize("p,nc", [(2, (3, 2, 2)), (3, (2, 2, 2)), (4, (2, 1, 2))])
