@@ -425,6 +425,7 @@ template <typename T> static const void *vanka_kernel(int p, int mtw)
     case 2: return vanka_kernel<T, 27>(mtw);
     case 3: return vanka_kernel<T, 64>(mtw);
     case 4: return vanka_kernel<T, 125>(mtw);
+    case 5: return vanka_kernel<T, 216>(mtw);
     default: return nullptr;
   }
 }
@@ -774,7 +775,7 @@ int stfem_vanka_create_partitioned(stfem_ctx *c, int nb, const double *Alpha, co
     return STFEM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   const int p = c->p, n = p + 1, nloc = n * n * n, m = nb * nloc;
-  if (m > VK_MAX_ROWS || p > 4) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 4 temporal blocks; the apply kernels are instantiated up to FE_Q(4)
+  if (m > VK_MAX_ROWS) return STFEM_ERR_UNSUPPORTED; // Q4 with more than 4 temporal blocks, Q5 with more than 2
   VK_TRY(hipSetDevice(c->device));
   stfem_vanka *v = new (std::nothrow) stfem_vanka;
   if (!v) return STFEM_ERR_OUT_OF_MEMORY;

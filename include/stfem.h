@@ -64,8 +64,8 @@ typedef struct {
 
 /* Replaces FE_Q<dim>(p) + QGauss<dim>(p+1) of tests/tp_01.cc:76-77. */
 typedef struct {
-  int32_t degree;       /* p, 1..5 (FE_Q(5): operator apply, diagonal, vectors, transfers and driver kernels; the tile sweep on every
-                         * mesh; no cell-patch smoother: stfem_vanka_create* return STFEM_ERR_UNSUPPORTED) */
+  int32_t degree;       /* p, 1..5 (FE_Q(5): the tile sweep on every mesh; cell-patch smoother for one or two temporal blocks,
+                         * i.e. cell blocks of up to 512 rows as for every degree) */
   int32_t n_q_points_1d; /* must be degree+1 */
   int32_t n_components; /* must be 1 (scalar path) */
   int32_t precision;    /* 0 = fp64 (the solver's Number, operators.cc:5-45), 1 = fp32 (the multigrid

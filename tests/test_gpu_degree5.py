@@ -1,7 +1,7 @@
 """FE_Q(5) in space (the reference's run-time degree: tests/tp_01.cc:76-78 builds FE_Q(fe_degree + 1), its golden tests/tp_01.output
 holds the k = 4 tables of FE_Q(5) x cG(4)): the operator apply, the diagonal and the space transfers of degree-5 contexts against the
 oracle.  Degree 5 runs the tile sweep on every mesh (the pencil sweep's planes do not fit a wave's registers); the cell-patch
-smoother has no degree-5 instantiation and says so."""
+smoother takes degree-5 blocks of one or two temporal blocks (512 rows per cell block at most)."""
 import importlib
 
 import numpy as np
@@ -126,11 +126,36 @@ def test_degree5_space_transfers(pf, ncf, pc, ncc, stfem):
     assert rel(out_c.download(), Uc + (P.T @ Uf.T).T) < 1e-13
 
 
+@pytest.mark.parametrize("number", ["double", "float"])
+@pytest.mark.parametrize("nc,ttype,r,mask,distort", [((3, 2, 2), 0, 1, 63, 0.0), ((2, 2, 3), 0, 2, 63 & ~48, 0.0), ((2, 2, 2), 1, 0, 63, 0.1)])
+def test_degree5_vanka_vs_oracle(nc, ttype, r, mask, distort, number, stfem):
+    """PreconditionVanka on FE_Q(5) cells (216 rows per temporal block: one and two blocks fit the apply kernel), block classes on
+    axis-aligned meshes and one block per cell on perturbed ones, against the dense restatement"""
+    from oracle import vanka_oracle
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(ttype, r, 0.05, 1)
+    nb = Alpha.shape[0]
+    verts = stfem.mesh_vertices(nc, distort=distort, seed=11) if distort else stfem.mesh_vertices(nc)
+    ctx = (stfem.MatrixFreeOperator(5, nc, vertices=verts, number=number, dirichlet_mask=mask) if distort else
+           stfem.MatrixFreeOperator(5, nc, number=number, dirichlet_mask=mask))
+    V = stfem.PreconditionVanka(ctx, Alpha, Beta)
+    ref = vanka_oracle.VankaOracle(5, nc, verts, mask, Alpha, Beta)
+    rng = np.random.default_rng(7)
+    X = rng.uniform(-1, 1, (nb, ctx.n_dofs))
+    if number == "float":
+        X = X.astype(np.float32).astype(np.float64)
+    src, dst = stfem.BlockVector(ctx, nb).upload(X), stfem.BlockVector(ctx, nb).upload(rng.uniform(-1, 1, (nb, ctx.n_dofs)))
+    V.vmult(dst, src)
+    Y = dst.download()
+    assert rel(Y, ref.vmult(X)) < (1e-10 if number == "double" else 5e-4)
+    V.vmult(dst, src)
+    assert np.array_equal(dst.download(), Y)
+
+
 def test_degree5_limits(stfem):
-    """what has no FE_Q(5) instantiation fails with a status, not with a wrong result: the cell-patch smoother (216-row blocks per
-    time dof), degree 6"""
+    """what has no FE_Q(5) instantiation fails with a status, not with a wrong result: cell blocks of more than 512 rows (three
+    temporal blocks of 216), degree 6"""
     ctx = stfem.MatrixFreeOperator(5, (2, 2, 2))
-    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 1, 0.1, 1)
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights(stfem.CGP, 3, 0.1, 1)
     with pytest.raises(stfem.StfemError):
         stfem.PreconditionVanka(ctx, Alpha, Beta)
     with pytest.raises(stfem.StfemError):

@@ -140,6 +140,7 @@ def _oracle_vcycle(oracle_mod, stfem, ttype, k, n, nsteps, p, ctype, pmg, distor
     (0, 2, 2, 2, 2, "space_or_time", False, 0.0),     # cG(2) Q2: h k t
     (0, 2, 2, 2, 3, "space_and_time", True, 0.0),     # interleaved h / p with k / tau, identity smoothers on the in-between levels
     (1, 0, 4, 4, 2, "space_or_time", False, 0.1),     # dG(0), four steps at once, perturbed mesh: h h t t
+    (0, 2, 2, 1, 5, "space_or_time", True, 0.0),      # FE_Q(5) x cG(2) with p-multigrid (432-row cell blocks on the finest level)
 ])
 def test_vcycle_vs_oracle(ttype, k, n, nsteps, p, ctype, pmg, distort, number, tmp_path, oracle_mod):
     from oracle import stmg_oracle
