@@ -196,8 +196,12 @@ double estimate_relaxation_stokes(const System &A, const PreconditionVankaStokes
 // PreconditionVanka per level, MGTwoLevelBlockTransfer with one space transfer per variable; include/stmg.h:1160-1419: GMG with
 // Multigrid, MGSmootherPrecondition around PreconditionRelaxation(Vanka), MGCoarseGridApplySmoother, PreconditionMG) over the
 // C-ABI: the velocity components are transferred as FE_Q(2) functions with the constraints of both levels, the pressure as a
-// FE_Q(1) function (stfem_transfer_*), every level smooths with relaxation sweeps of the two-variable Vanka smoother.  Space levels
-// only (the temporal blocks are the same on every level).
+// FE_Q(1) function (stfem_transfer_*), every level smooths with relaxation sweeps of the two-variable Vanka smoother.  The first
+// constructor coarsens in space only (the temporal blocks are the same on every level); the second takes the reference's level
+// sequence (tests/tp_03stokes.cc:294-326: MGType h, k, tau from get_mg_sequence) - a k level lowers the temporal degree, a tau
+// level halves the time steps per slab, both with the time transfers of MGTwoLevelTransferTime applied per variable
+// (include/stmg.h:557-600: MGTwoLevelBlockTransfer with the time matrices), and every level has its own temporal matrices
+// (get_fe_time_weights_stokes of its degree, step count and step size) and block structure.
 template <int dim> class GMGStokes {
 public:
   struct AdditionalData {
@@ -210,35 +214,51 @@ public:
   GMGStokes(const Mesh &mesh, unsigned n_levels, double viscosity, const FullMatrix<double> &Alpha, const FullMatrix<double> &Beta,
             const BlockSlice &slice, const AdditionalData &data = AdditionalData(), const std::set<boundary_id> &weak_boundary_ids = {},
             bool dg_pressure = false)
-    : data_(data), slice_(slice), Alpha_(Alpha), Beta_(Beta)
+    : data_(data)
   {
     if (n_levels < 1) throw std::invalid_argument("GMGStokes: at least one level");
     dg_ = dg_pressure;
     levels_.resize(n_levels);
     for (unsigned l = 0; l < n_levels; ++l) {
+      levels_[l].halvings = n_levels - 1 - l;
+      levels_[l].Alpha = Alpha;
+      levels_[l].Beta = Beta;
+      levels_[l].slice = slice;
+      levels_[l].from_below = MGType::h;
+    }
+    build(mesh, viscosity, weak_boundary_ids, TimeStepType::CGP);
+  }
+  // mg_type_level[l]: how level l + 1 (finer) arises from level l, finest last, as get_mg_sequence returns it (h, k and tau; the
+  // Stokes element has no p levels); poly_time_sequence: the temporal degrees, ascending (get_poly_mg_sequence); the finest level has
+  // degree poly_time_sequence.back(), n_timesteps_at_once steps of size time_step_size per slab
+  GMGStokes(const Mesh &mesh, const std::vector<MGType> &mg_type_level, const std::vector<unsigned> &poly_time_sequence, TimeStepType type,
+            double time_step_size, unsigned n_timesteps_at_once, double viscosity, const AdditionalData &data = AdditionalData(),
+            const std::set<boundary_id> &weak_boundary_ids = {}, bool dg_pressure = false)
+    : data_(data)
+  {
+    dg_ = dg_pressure;
+    const unsigned n_levels = unsigned(mg_type_level.size()) + 1;
+    levels_.resize(n_levels);
+    const auto blk = get_blk_indices(type, n_timesteps_at_once, 2, n_levels, mg_type_level, poly_time_sequence);
+    auto p_mg = poly_time_sequence.rbegin();
+    unsigned halvings = 0;
+    for (unsigned l = n_levels; l-- > 0;) {
       Level &L = levels_[l];
-      L.mesh = mesh;
-      for (int d = 0; d < 3; ++d) {
-        const int f = 1 << (n_levels - 1 - l);
-        if (mesh.ncell[d] % f) throw std::invalid_argument("GMGStokes: the cell counts must be divisible by 2^(levels - 1)");
-        L.mesh.ncell[d] = mesh.ncell[d] / f;
-      }
-      L.K = std::make_unique<StokesMatrixFreeOperator<dim, double>>(L.mesh, 2, viscosity, weak_boundary_ids, std::set<boundary_id>(), 20.0, 10.0, 0.0, 0.0, 0.0,
-                                                                   dg_pressure);
-      L.spaces = std::make_shared<StokesSpaces>(L.mesh, L.K->handle());
-      L.A = std::make_unique<SystemMatrixStokes<dim, double>>(*L.K, Alpha_, Beta_, slice_);
-      L.system = std::make_unique<StokesSystem<dim, double>>(*L.A, L.spaces, L.K->handle(), slice_);
-      L.vanka = std::make_unique<PreconditionVankaStokes<double>>(*L.K, Alpha_, Beta_, slice_);
-      L.omega = data.relaxation != 0.0 ? data.relaxation : estimate_relaxation_stokes(*L.system, *L.vanka, 20, 1.0);
-      L.relax = std::make_unique<PreconditionRelaxationStokes<StokesSystem<dim, double>>>(*L.system, *L.vanka, L.omega, data.smoothing_degree);
-      L.system->initialize_dof_vector(L.defect);
-      L.system->initialize_dof_vector(L.solution);
-      L.system->initialize_dof_vector(L.t);
-      if (l > 0) {
-        L.tr_u = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q2, levels_[l - 1].spaces->q2);
-        if (!dg_) L.tr_p = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q1, levels_[l - 1].spaces->q1);
+      L.halvings = halvings;
+      L.slice = blk[l];
+      const auto w = get_fe_time_weights_stokes<double>(type, *p_mg, time_step_size, n_timesteps_at_once);
+      L.Alpha = w[0];
+      L.Beta = w[1];
+      if (l == 0) break;
+      L.from_below = mg_type_level[l - 1];
+      switch (mg_type_level[l - 1]) {
+        case MGType::h: ++halvings; break;
+        case MGType::k: ++p_mg; break;
+        case MGType::tau: n_timesteps_at_once /= 2; time_step_size *= 2; break;
+        default: throw std::invalid_argument("GMGStokes: h, k and tau levels");
       }
     }
+    build(mesh, viscosity, weak_boundary_ids, type);
   }
   const StokesSystem<dim, double> &finest_system() const { return *levels_.back().system; }
   const StokesMatrixFreeOperator<dim, double> &finest_operator() const { return *levels_.back().K; }
@@ -252,9 +272,10 @@ public:
     TraceRange scope("gmg");
     const unsigned top = unsigned(levels_.size()) - 1;
     // (the caller's vectors may live on contexts of their own for the same mesh: view their blocks through this level's spaces)
-    for (unsigned b = 0; b < slice_.n_blocks(); ++b) axpby(1.0, foreign_view(src, b), 0.0, levels_[top].defect.view(b));
+    const unsigned nb = levels_[top].slice.n_blocks();
+    for (unsigned b = 0; b < nb; ++b) axpby(1.0, foreign_view(src, b), 0.0, levels_[top].defect.view(b));
     level_v_step(top);
-    for (unsigned b = 0; b < slice_.n_blocks(); ++b) {
+    for (unsigned b = 0; b < nb; ++b) {
       BlockVectorT<double> d = foreign_view(dst, b);
       axpby(1.0, levels_[top].solution.view(b), 0.0, d);
     }
@@ -263,6 +284,11 @@ public:
 private:
   struct Level {
     Mesh mesh;
+    unsigned halvings = 0;            // of the finest mesh's cell counts
+    FullMatrix<double> Alpha, Beta;   // the level's temporal matrices and block structure
+    BlockSlice slice;
+    MGType from_below = MGType::h;    // the transfer between this level and the one below
+    FullMatrix<double> time_prolongation, time_restriction; // k / tau: one variable's blocks (BlockSlice(steps, 1, dofs) order)
     std::unique_ptr<StokesMatrixFreeOperator<dim, double>> K;
     std::shared_ptr<StokesSpaces> spaces;
     std::unique_ptr<SystemMatrixStokes<dim, double>> A;
@@ -273,12 +299,72 @@ private:
     double omega = 1.0;
     mutable StokesBlockVector defect, solution, t, tmp;
   };
+  void build(const Mesh &mesh, double viscosity, const std::set<boundary_id> &weak_boundary_ids, TimeStepType type)
+  {
+    const unsigned n_levels = unsigned(levels_.size());
+    for (unsigned l = 0; l < n_levels; ++l) {
+      Level &L = levels_[l];
+      L.mesh = mesh;
+      for (int d = 0; d < 3; ++d) {
+        const int f = 1 << L.halvings;
+        if (mesh.ncell[d] % f) throw std::invalid_argument("GMGStokes: the cell counts must be divisible by 2^(space levels - 1)");
+        L.mesh.ncell[d] = mesh.ncell[d] / f;
+      }
+      L.K = std::make_unique<StokesMatrixFreeOperator<dim, double>>(L.mesh, 2, viscosity, weak_boundary_ids, std::set<boundary_id>(), 20.0, 10.0, 0.0, 0.0, 0.0,
+                                                                   dg_);
+      L.spaces = std::make_shared<StokesSpaces>(L.mesh, L.K->handle());
+      L.A = std::make_unique<SystemMatrixStokes<dim, double>>(*L.K, L.Alpha, L.Beta, L.slice);
+      L.system = std::make_unique<StokesSystem<dim, double>>(*L.A, L.spaces, L.K->handle(), L.slice);
+      L.vanka = std::make_unique<PreconditionVankaStokes<double>>(*L.K, L.Alpha, L.Beta, L.slice);
+      L.omega = data_.relaxation != 0.0 ? data_.relaxation : estimate_relaxation_stokes(*L.system, *L.vanka, 20, 1.0);
+      L.relax = std::make_unique<PreconditionRelaxationStokes<StokesSystem<dim, double>>>(*L.system, *L.vanka, L.omega, data_.smoothing_degree);
+      L.system->initialize_dof_vector(L.defect);
+      L.system->initialize_dof_vector(L.solution);
+      L.system->initialize_dof_vector(L.t);
+      if (l == 0) continue;
+      const Level &C = levels_[l - 1];
+      if (L.from_below == MGType::h) {
+        L.tr_u = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q2, C.spaces->q2);
+        if (!dg_) L.tr_p = std::make_unique<MGTwoLevelTransfer<double>>(L.spaces->q1, C.spaces->q1);
+      } else { // (restrict = transposed prolongation: the reference's default, parameters.h:29)
+        const MGTwoLevelTransferTime<double> tt(BlockSlice(L.slice.n_timesteps_at_once(), 1, L.slice.n_timedofs()),
+                                                BlockSlice(C.slice.n_timesteps_at_once(), 1, C.slice.n_timedofs()), type, true, L.from_below);
+        L.time_prolongation = tt.prolongation();
+        L.time_restriction = tt.restriction();
+      }
+    }
+  }
+  // dst (+)= (matrix x identity) src on the blocks of every variable: matrix acts between the (step, time dof) blocks of one variable
+  void time_transfer(const Level &D, StokesBlockVector &dst, const FullMatrix<double> &matrix, const Level &S, const StokesBlockVector &src) const
+  {
+    for (unsigned v = 0; v < 2; ++v) {
+      const unsigned ncomp = v == 0 ? 3 : 1;
+      const size_t len = v == 0 ? size_t(stfem_stokes_n_velocity_dofs(D.K->handle())) : 0;
+      auto gather = [&](const Level &L, const StokesBlockVector &x) {
+        std::vector<void *> ptrs;
+        for (unsigned it = 0; it < L.slice.n_timesteps_at_once(); ++it)
+          for (unsigned id = 0; id < L.slice.n_timedofs(); ++id)
+            for (unsigned c = 0; c < ncomp; ++c) ptrs.push_back(x.blocks()[L.slice.index(it, v, id)].data() + c * len);
+        return ptrs;
+      };
+      std::vector<void *> pd = gather(D, dst), ps = gather(S, src);
+      BlockVectorT<double> vd, vs;
+      const auto &ctx = v == 0 ? D.spaces->q2 : D.spaces->q1; // (the same mesh on both levels: one context serves both)
+      vd.wrap(ctx, pd.data(), unsigned(pd.size()));
+      vs.wrap(ctx, ps.data(), unsigned(ps.size()));
+      std::vector<double> a(pd.size() * ps.size(), 0.0);
+      for (unsigned i = 0; i < matrix.m(); ++i)
+        for (unsigned j = 0; j < matrix.n(); ++j)
+          for (unsigned c = 0; c < ncomp; ++c) a[size_t(i * ncomp + c) * ps.size() + j * ncomp + c] = matrix(i, j);
+      check(stfem_tensorproduct_add(ctx->h, int(pd.size()), int(ps.size()), a.data(), vd.handle(), vs.handle(), nullptr), "GMGStokes: time transfer");
+    }
+  }
   BlockVectorT<double> foreign_view(const StokesBlockVector &x, unsigned b) const
   {
     const StokesSpaces &sp = *levels_.back().spaces;
     BlockVectorT<double> v;
     double *base = x.blocks()[b].data();
-    if (slice_.decompose(b)[1] == 0) {
+    if (levels_.back().slice.decompose(b)[1] == 0) {
       const size_t nu = size_t(stfem_stokes_n_velocity_dofs(levels_.back().K->handle()));
       void *ptrs[3] = {base, base + nu, base + 2 * nu};
       v.wrap(sp.q2, ptrs, 3);
@@ -319,30 +405,32 @@ private:
     L.system->vmult(L.t, L.solution);
     axpby(1.0, L.defect, -1.0, L.t);
     set_zero(C.defect);
-    for (unsigned b = 0; b < slice_.n_blocks(); ++b) { // MGTwoLevelBlockTransfer::restrict_and_add: block by block with its variable's transfer
-      if (slice_.decompose(b)[1] == 1 && dg_) {
+    const BlockSlice &slice = L.slice;
+    const bool in_time = L.from_below != MGType::h; // MGTwoLevelBlockTransfer with the time matrices, or one space transfer per variable
+    if (in_time) time_transfer(C, C.defect, L.time_restriction, L, L.t);
+    for (unsigned b = 0; b < slice.n_blocks() && !in_time; ++b) { // restrict_and_add: block by block with its variable's transfer
+      if (slice.decompose(b)[1] == 1 && dg_) {
         check(stfem_stokes_dgp_restrict(L.K->handle(), C.K->handle(), C.defect.blocks()[b].data(), L.t.blocks()[b].data(), 1, nullptr), "GMGStokes: restrict_and_add");
         continue;
       }
-      const MGTwoLevelTransfer<double> &tr = slice_.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
+      const MGTwoLevelTransfer<double> &tr = slice.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
       check(stfem_transfer_restrict(tr.handle(), C.defect.view(b).handle(), L.t.view(b).handle(), 1, nullptr), "GMGStokes: restrict_and_add");
     }
     level_v_step(level - 1);
-    for (unsigned b = 0; b < slice_.n_blocks(); ++b) {
-      if (slice_.decompose(b)[1] == 1 && dg_) {
+    if (in_time) time_transfer(L, L.solution, L.time_prolongation, C, C.solution);
+    for (unsigned b = 0; b < slice.n_blocks() && !in_time; ++b) {
+      if (slice.decompose(b)[1] == 1 && dg_) {
         check(stfem_stokes_dgp_prolongate(L.K->handle(), C.K->handle(), L.solution.blocks()[b].data(), C.solution.blocks()[b].data(), 1, nullptr),
               "GMGStokes: prolongate_and_add");
         continue;
       }
-      const MGTwoLevelTransfer<double> &tr = slice_.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
+      const MGTwoLevelTransfer<double> &tr = slice.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
       check(stfem_transfer_prolongate(tr.handle(), L.solution.view(b).handle(), C.solution.view(b).handle(), 1, nullptr), "GMGStokes: prolongate_and_add");
     }
     smooth(level, false);
   }
   AdditionalData data_;
   bool dg_ = false;
-  BlockSlice slice_;
-  FullMatrix<double> Alpha_, Beta_;
   std::vector<Level> levels_;
 };
 

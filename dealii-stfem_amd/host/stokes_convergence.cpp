@@ -6,9 +6,11 @@
 // velocity is the curl of psi e_z, psi = sin t (sin pi x sin pi y sin pi z)^2, the pressure sin t cos pi x cos pi y cos pi z.
 // With mg=<levels> the preconditioner is one V-cycle of the geometric multigrid of the reference's Stokes runs (GMGStokes in
 // host/stfem/stokes_solver.h: <levels> space levels, relaxation sweeps of the Vanka smoother on every level, 2^(levels - 1 - l) smoothing
-// steps on level l); the errors do not depend on the preconditioner, the iteration counts do.
+// steps on level l); with stmg=1 in addition the levels in time of the reference's sequence (get_mg_sequence as tests/tp_03stokes.cc:294-312
+// calls it: the temporal degree goes down to 1 (cG) / 0 (dG) by bisection, space_or_time unless coarsening=space_and_time).  The errors do
+// not depend on the preconditioner, the iteration counts do.
 // Usage: stokes_convergence <type 0 = cG | 1 = dG> <k> <refinement> [vanka sweeps = 3] [omega = 0: estimated] [viscosity = 1] [cells per direction]
-//                           [end_time = 1] [mg=<levels>] [dg=1]
+//                           [end_time = 1] [mg=<levels>] [stmg=1] [coarsening=space_and_time] [dg=1]
 // Prints: cells u-dofs p-dofs t-dofs  u:Linf-Linf  u:L2-L2  u:L2-H1semi  p:L2-L2  gmres-iterations-per-solve
 #include "stfem/stokes_solver.h"
 
@@ -32,11 +34,14 @@ inline double d2B(double s) { return -4 * PI * PI * B(s); }
 int main(int argc_all, char **argv_all)
 {
   unsigned mg_levels = 0;
+  bool stmg = false, space_and_time = false;
   bool dg_pressure = false; // dg=1: FE_DGP(1) pressure, the reference's default (tests/json/stokes.json: dGPressure = true)
   std::vector<char *> pos;
   for (int i = 0; i < argc_all; ++i) {
     if (i > 0 && std::strncmp(argv_all[i], "mg=", 3) == 0) mg_levels = unsigned(std::atoi(argv_all[i] + 3));
     else if (i > 0 && std::strncmp(argv_all[i], "dg=", 3) == 0) dg_pressure = std::atoi(argv_all[i] + 3) != 0;
+    else if (i > 0 && std::strncmp(argv_all[i], "stmg=", 5) == 0) stmg = std::atoi(argv_all[i] + 5) != 0;
+    else if (i > 0 && std::strcmp(argv_all[i], "coarsening=space_and_time") == 0) space_and_time = true;
     else pos.push_back(argv_all[i]);
   }
   const int argc = int(pos.size());
@@ -118,7 +123,15 @@ int main(int argc_all, char **argv_all)
       GMGStokes<3>::AdditionalData ad;
       ad.smoothing_degree = sweeps;
       ad.relaxation = omega_arg;
-      gmg = std::make_unique<GMGStokes<3>>(mesh, mg_levels, nu, w[0], w[1], slice, ad, std::set<boundary_id>(), dg_pressure);
+      if (stmg) {
+        const auto poly_time = get_poly_mg_sequence(k, type == TimeStepType::CGP ? 1u : 0u, PolynomialCoarseningSequenceType::bisect);
+        const auto seq = get_mg_sequence(mg_levels, poly_time, std::vector<unsigned>{2}, 1, 1, MGType::tau,
+                                         space_and_time ? CoarseningType::space_and_time : CoarseningType::space_or_time, false, false, true);
+        std::fprintf(stderr, "levels:");
+        for (MGType t : seq) std::fprintf(stderr, " %c", char(t));
+        std::fprintf(stderr, "\n");
+        gmg = std::make_unique<GMGStokes<3>>(mesh, seq, poly_time, type, tau, 1, nu, ad, std::set<boundary_id>(), dg_pressure);
+      } else gmg = std::make_unique<GMGStokes<3>>(mesh, mg_levels, nu, w[0], w[1], slice, ad, std::set<boundary_id>(), dg_pressure);
       for (unsigned l = 0; l < gmg->n_levels(); ++l) std::fprintf(stderr, "level %u: relaxation %.4f\n", l, gmg->relaxation(l));
     } else
       std::fprintf(stderr, "relaxation %.4f\n", omega);

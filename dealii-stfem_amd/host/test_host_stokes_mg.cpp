@@ -1,17 +1,20 @@
 // C++ caller of the Stokes multigrid mirror (GMGStokes, host/stfem/stokes_solver.h): one V-cycle applied to seeded vectors, written
 // out for the Python test that compares it with the numpy V-cycle of oracle/stmg_oracle.py on dense level matrices.
-//   test_host_stokes_mg n levels type r viscosity smoothing_degree omega variable out.bin [dg_pressure]
+//   test_host_stokes_mg n levels type r viscosity smoothing_degree omega variable out.bin [dg_pressure [sequence steps]]
+// sequence: the level transitions coarse to fine, e.g. "hk" (h, then k: the temporal degree rises by one per k towards the finest
+// level, a t doubles the time steps per slab); `levels` is ignored then.  steps: time steps per slab on the finest level.
 #include "stfem/stokes_solver.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <random>
 
 using namespace stfem;
 
 int main(int argc, char **argv)
 {
-  if (argc != 10 && argc != 11) return 2;
+  if (argc != 10 && argc != 11 && argc != 13) return 2;
   try {
     Mesh mesh;
     mesh.ncell[0] = mesh.ncell[1] = mesh.ncell[2] = std::atoi(argv[1]);
@@ -24,10 +27,23 @@ int main(int argc, char **argv)
     ad.relaxation = std::atof(argv[7]);
     ad.variable = std::atoi(argv[8]) != 0;
     const unsigned nt = type == TimeStepType::CGP ? r : r + 1;
-    const BlockSlice slice(1, 2, nt);
-    const auto w = get_fe_time_weights_stokes<double>(type, r, 1.0 / 16, 1);
-    const bool dg = argc == 11 && std::atoi(argv[10]) != 0;
-    GMGStokes<3> gmg(mesh, levels, nu, w[0], w[1], slice, ad, std::set<boundary_id>(), dg);
+    const unsigned steps = argc == 13 ? unsigned(std::atoi(argv[12])) : 1;
+    const BlockSlice slice(steps, 2, nt);
+    const auto w = get_fe_time_weights_stokes<double>(type, r, 1.0 / 16, steps);
+    const bool dg = argc >= 11 && std::atoi(argv[10]) != 0;
+    std::unique_ptr<GMGStokes<3>> gmg_ptr;
+    if (argc == 13) {
+      std::vector<MGType> seq;
+      unsigned n_k = 0;
+      for (const char *c = argv[11]; *c; ++c) {
+        seq.push_back(MGType(*c));
+        n_k += *c == 'k';
+      }
+      std::vector<unsigned> degrees;
+      for (unsigned d = r - n_k; d <= r; ++d) degrees.push_back(d);
+      gmg_ptr = std::make_unique<GMGStokes<3>>(mesh, seq, degrees, type, 1.0 / 16, steps, nu, ad, std::set<boundary_id>(), dg);
+    } else gmg_ptr = std::make_unique<GMGStokes<3>>(mesh, levels, nu, w[0], w[1], slice, ad, std::set<boundary_id>(), dg);
+    GMGStokes<3> &gmg = *gmg_ptr;
     StokesBlockVector x, y;
     gmg.finest_system().initialize_dof_vector(x);
     gmg.finest_system().initialize_dof_vector(y);

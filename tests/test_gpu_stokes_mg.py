@@ -41,19 +41,68 @@ def _dgp_prolongation(ncc):
     return sp.coo_matrix((vals, (rows, cols)), shape=(nf, ncl)).tocsr()
 
 
-@pytest.mark.parametrize("n,levels,ttype,r,nu,degree,omega,variable,dg", [
-    (4, 2, 0, 1, 1.0, 1, 0.6, 1, 0),    # cG(1): one time dof; 4^3 -> 2^3 cells
-    (4, 2, 1, 1, 0.5, 2, 0.5, 1, 0),    # dG(1): two time dofs, two sweeps per smoothing step (a third level would be one cell: singular blocks)
-    (4, 2, 0, 2, 1.0, 1, 0.6, 0, 0),    # cG(2), one smoothing step on every level
-    (4, 2, 0, 1, 1.0, 1, 0.4, 1, 1),    # FE_DGP(1) pressure (the reference's default): the pressure transfer is the cell-wise embedding
+def _stokes_level(o, vanka_oracle, stfem, nc, ttype, r, tau, ns, nu, dg, omega, degree):
+    """dense matrix and the smoother of one level; -> (dict for stmg_oracle.Multigrid, block sizes, BlockSlice order of the blocks)"""
+    nt = r if ttype == 0 else r + 1
+    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(ttype, r, tau, ns)
+    var = [(b // nt) % 2 for b in range(2 * nt * ns)]  # BlockSlice(ns, 2, nt), variable-major: [step][variable][time dof]
+    verts = stfem.mesh_vertices(nc)
+    so = o.StokesOracle(nc, verts, 63, nu, dg_pressure=bool(dg))
+    bs = [3 * so.n_u if v == 0 else so.n_p for v in var]
+    off = np.concatenate([[0], np.cumsum(bs)])
+    nb, N = len(bs), off[-1]
+    A = np.zeros((N, N))
+    e = [np.zeros(m) for m in bs]
+    for b in range(nb):
+        for j in range(bs[b]):
+            e[b][j] = 1.0
+            A[:, off[b] + j] = np.concatenate(so.st_vmult(Alpha, Beta, ns, nt, e))
+            e[b][j] = 0.0
+    vk = vanka_oracle.StokesVankaOracle(nc, verts, 63, nu, var, Alpha, Beta, dg_pressure=bool(dg))
+
+    def smoother(rv):
+        return np.concatenate(vk.vmult([rv[off[b]:off[b + 1]] for b in range(nb)]))
+
+    return dict(A=A, smoother=smoother, omega=omega, n_iterations=degree), bs, (ns, nt)
+
+
+def _time_transfer_matrix(Pt, fine, coarse, bs_f, bs_c):
+    """Pt between the (step, time dof) blocks of ONE variable, placed on the blocks of both variables of the two BlockSlices"""
+    (ns_f, nt_f), (ns_c, nt_c) = fine, coarse
+    rows = [[None] * len(bs_c) for _ in bs_f]
+    for i, m in enumerate(bs_f):
+        for j, k in enumerate(bs_c):
+            rows[i][j] = sp.csr_matrix((m, k))
+    for v in range(2):
+        for itf in range(ns_f):
+            for idf in range(nt_f):
+                for itc in range(ns_c):
+                    for idc in range(nt_c):
+                        w = Pt[itf * nt_f + idf, itc * nt_c + idc]
+                        if w != 0.0:
+                            i, j = itf * 2 * nt_f + v * nt_f + idf, itc * 2 * nt_c + v * nt_c + idc
+                            rows[i][j] = w * sp.identity(bs_f[i], format="csr")
+    return sp.bmat(rows, format="csr")
+
+
+@pytest.mark.parametrize("n,levels,ttype,r,nu,degree,omega,variable,dg,seq,steps", [
+    (4, 2, 0, 1, 1.0, 1, 0.6, 1, 0, None, 1),    # cG(1): one time dof; 4^3 -> 2^3 cells
+    (4, 2, 1, 1, 0.5, 2, 0.5, 1, 0, None, 1),    # dG(1): two time dofs, two sweeps per smoothing step (a third level would be one cell: singular blocks)
+    (4, 2, 0, 2, 1.0, 1, 0.6, 0, 0, None, 1),    # cG(2), one smoothing step on every level
+    (4, 2, 0, 1, 1.0, 1, 0.4, 1, 1, None, 1),    # FE_DGP(1) pressure (the reference's default): the pressure transfer is the cell-wise embedding
+    (4, 0, 0, 2, 1.0, 1, 0.5, 1, 0, "hk", 1),    # the reference's sequence for cG(2): coarsest 2^3 cells cG(1), h, then k to cG(2)
+    (4, 0, 1, 1, 1.0, 1, 0.4, 1, 1, "kh", 1),    # dG(1) -> dG(0) on the coarse mesh last, FE_DGP(1) pressure
+    (2, 0, 0, 1, 1.0, 1, 0.5, 1, 0, "t", 2),     # two time steps per slab -> one (tau level), same mesh
 ])
-def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variable, dg, tmp_path):
+def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variable, dg, seq, steps, tmp_path):
     from oracle import oracle as o, stmg_oracle as mg, vanka_oracle
     import importlib
     stfem = importlib.import_module("dealii-stfem_amd")
     out = str(tmp_path / "vc.bin")
-    res = subprocess.run([_exe("test_host_stokes_mg"), str(n), str(levels), str(ttype), str(r), str(nu), str(degree), str(omega), str(variable), out, str(dg)],
-                         capture_output=True, text=True, timeout=600)
+    args = [_exe("test_host_stokes_mg"), str(n), str(levels), str(ttype), str(r), str(nu), str(degree), str(omega), str(variable), out, str(dg)]
+    if seq is not None:
+        args += [seq, str(steps)]
+    res = subprocess.run(args, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     raw = np.fromfile(out, dtype=np.uint8)
     nb = int(np.frombuffer(raw[:8], dtype=np.uint64)[0])
@@ -66,40 +115,35 @@ def test_stokes_vcycle_vs_oracle(n, levels, ttype, r, nu, degree, omega, variabl
     for m in sizes:
         Y.append(np.frombuffer(raw[pos:pos + 8 * m], dtype=np.float64).copy()); pos += 8 * m
     nt = r if ttype == 0 else r + 1
-    assert nb == 2 * nt
-    Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(ttype, r, 1.0 / 16, 1)
-    var = [0] * nt + [1] * nt  # BlockSlice(1, 2, nt), variable-major
-    lv, transfers = [], [None]
-    for l in range(levels):
-        nl = n >> (levels - 1 - l)
-        nc = (nl, nl, nl)
-        verts = stfem.mesh_vertices(nc)
-        so = o.StokesOracle(nc, verts, 63, nu, dg_pressure=bool(dg))
-        Nu, Np = so.n_u, so.n_p
-        bs = [3 * Nu] * nt + [Np] * nt
-        off = np.concatenate([[0], np.cumsum(bs)])
-        N = off[-1]
-        A = np.zeros((N, N))
-        e = [np.zeros(s) for s in bs]
-        for b in range(nb):
-            for j in range(bs[b]):
-                e[b][j] = 1.0
-                col = so.st_vmult(Alpha, Beta, 1, nt, e)
-                A[:, off[b] + j] = np.concatenate(col)
-                e[b][j] = 0.0
-        vk = vanka_oracle.StokesVankaOracle(nc, verts, 63, nu, var, Alpha, Beta, dg_pressure=bool(dg))
-
-        def smoother(rv, vk=vk, off=off):
-            return np.concatenate(vk.vmult([rv[off[b]:off[b + 1]] for b in range(nb)]))
-
-        lv.append(dict(A=A, smoother=smoother, omega=omega, n_iterations=degree))
-        if l > 0:
-            ncc = (nl // 2,) * 3
+    assert nb == 2 * nt * steps
+    kinds = list(seq) if seq is not None else ["h"] * (levels - 1)  # transitions, coarse to fine
+    # (cells, temporal degree, step size, steps per slab) of every level, finest last
+    state, cfg = (n, r, 1.0 / 16, steps), []
+    for kind in reversed(kinds):
+        cfg.append(state)
+        nl, rl, tau, ns = state
+        state = (nl // 2, rl, tau, ns) if kind == "h" else ((nl, rl - 1, tau, ns) if kind == "k" else (nl, rl, 2 * tau, ns // 2))
+    cfg.append(state)
+    cfg.reverse()
+    lv, transfers, shapes = [], [None], []
+    for l, (nl, rl, tau, ns) in enumerate(cfg):
+        level, bs, order = _stokes_level(o, vanka_oracle, stfem, (nl, nl, nl), ttype, rl, tau, ns, nu, dg, omega, degree)
+        lv.append(level)
+        shapes.append((bs, order))
+        if l == 0:
+            continue
+        kind, (bs_c, order_c) = kinds[l - 1], shapes[l - 1]
+        if kind == "h":
+            nc, ncc = (nl, nl, nl), (nl // 2,) * 3
             Pu = mg.space_prolongation(2, nc, 63, 2, ncc, 63)
             Pp = _dgp_prolongation(ncc) if dg else mg.space_prolongation(1, nc, 0, 1, ncc, 0)
-            blocks = [sp.block_diag([Pu, Pu, Pu]) if v == 0 else Pp for v in var]
-            P = sp.block_diag(blocks).tocsr()
-            transfers.append((P, P.T.tocsr()))
+            nt_l = order[1]
+            P = sp.block_diag([sp.block_diag([Pu, Pu, Pu]) if (b // nt_l) % 2 == 0 else Pp for b in range(len(bs))]).tocsr()
+        else:
+            Pt, _ = mg.time_transfer(ttype, kind, rl, cfg[l - 1][1], ns)
+            P = _time_transfer_matrix(Pt, order, order_c, bs, bs_c)
+        transfers.append((P, P.T.tocsr()))
+    assert [len(x) for x in X] == shapes[-1][0]
     want = mg.Multigrid(lv, transfers, variable=bool(variable), steps=1).vmult(np.concatenate(X))
     got = np.concatenate(Y)
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
@@ -122,3 +166,19 @@ def test_stokes_driver_with_multigrid():
     assert np.allclose(plain[4:8], mg2[4:8], rtol=1e-7, atol=1e-10)
     assert mg2[8] < 0.8 * plain[8], (plain[8], mg2[8])
     assert mg3[8] < 1.5 * mg2[8] + 2, (mg2[8], mg3[8])
+
+
+def test_stokes_driver_with_space_time_levels():
+    """cG(2): the reference's level sequence (h levels, then the k level from cG(1) to cG(2)) as preconditioner gives the rows of the
+    space-only multigrid and of the smoother alone (the solution does not depend on the preconditioner)"""
+    exe = _exe("stokes_convergence")
+    rows, seqs = [], []
+    for extra in ([], ["mg=2"], ["mg=2", "stmg=1"], ["mg=2", "stmg=1", "coarsening=space_and_time"]):
+        res = subprocess.run([exe, "0", "2", "2", "2", "0", "1.0", "4", "0.125"] + extra, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout + res.stderr
+        rows.append([float(v) for v in res.stdout.split()])
+        seqs.append([ln.split(":")[1].split() for ln in res.stderr.splitlines() if ln.startswith("levels:")])
+    assert seqs[2] == [["h", "k"]] and seqs[3] in ([["h", "k"]], [["k", "h"]])
+    for r in rows[1:]:
+        assert np.allclose(rows[0][4:8], r[4:8], rtol=1e-7, atol=1e-10)
+        assert r[8] < rows[0][8]
