@@ -540,38 +540,48 @@ __global__ __launch_bounds__(256, NO <= 2 ? 3 : 2) void stokes_grad_kernel(const
           for (int c = 0; c < 3; ++c) acc[o][c] = fma(P.wKu[o][s], g[c], acc[o][c]);
     }
   } else {
-    // FE_DGP(1): the node's cells (per direction: the cell it is node a of), four functions each
-    int c0[3], na[3], aa[3][2];
+    // FE_DGP(1), four functions per cell.  Per direction the node lies in up to two cells: slot 0 = the cell it is local node 1 (odd
+    // index) or 2 (even index) of, slot 1 = the cell above an even node (local node 0).  A missing cell keeps a clamped index and
+    // zero weights, so that the 8 x 4 coefficient loads are independent and the loops free of branches and of indexed reads of the
+    // kernel arguments (round 3: the divergent loops over run-time slot counts took 55 us on 64^3 cells)
+    int cell[3][2];
+    double wN0[3][2], wN1[3][2], wC0[3][2], wC1[3][2];
+#pragma unroll
     for (int d = 0; d < 3; ++d) {
-      if (idx[d] & 1) { c0[d] = idx[d] >> 1; na[d] = 1; aa[d][0] = 1; aa[d][1] = 1; }
-      else {
-        c0[d] = (idx[d] >> 1) - 1; // vertex: node 2 of the cell below, node 0 of the cell above
-        aa[d][0] = 2; aa[d][1] = 0;
-        na[d] = 2;
-      }
+      const int half = idx[d] >> 1;
+      const bool odd = idx[d] & 1;
+      const int below = odd ? half : half - 1;
+      const bool v0 = below >= 0, v1 = !odd && half < nc[d];
+      cell[d][0] = max(below, 0);
+      cell[d][1] = min(half, nc[d] - 1);
+      const double n0 = odd ? P.N[1][0] : P.N[2][0], n1 = odd ? P.N[1][1] : P.N[2][1];
+      const double c0 = odd ? P.C[1][0] : P.C[2][0], c1 = odd ? P.C[1][1] : P.C[2][1];
+      wN0[d][0] = v0 ? P.h[d] * n0 : 0.0;
+      wN1[d][0] = v0 ? P.h[d] * n1 : 0.0;
+      wC0[d][0] = v0 ? c0 : 0.0;
+      wC1[d][0] = v0 ? c1 : 0.0;
+      wN0[d][1] = v1 ? P.h[d] * P.N[0][0] : 0.0;
+      wN1[d][1] = v1 ? P.h[d] * P.N[0][1] : 0.0;
+      wC0[d][1] = v1 ? P.C[0][0] : 0.0;
+      wC1[d][1] = v1 ? P.C[0][1] : 0.0;
     }
     _Pragma("unroll 1") for (int s = 0; s < P.nsrc; ++s) { // (a run-time loop: only the destination loops need compile-time bounds)
       double g[3] = {0, 0, 0};
-      for (int ez = 0; ez < na[2]; ++ez) {
-        const int cz = c0[2] + ez, az = aa[2][ez];
-        if (cz < 0 || cz >= P.ncz) continue;
-        for (int ey = 0; ey < na[1]; ++ey) {
-          const int cy = c0[1] + ey, ay = aa[1][ey];
-          if (cy < 0 || cy >= P.ncy) continue;
-          for (int ex = 0; ex < na[0]; ++ex) {
-            const int cx = c0[0] + ex, ax = aa[0][ex];
-            if (cx < 0 || cx >= P.ncx) continue;
-            const double *pc = P.p[s] + 4 * (cx + (long long)P.ncx * (cy + (long long)P.ncy * cz));
+#pragma unroll
+      for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+        for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+          for (int ex = 0; ex < 2; ++ex) {
+            const double *pc = P.p[s] + 4 * (cell[0][ex] + (long long)P.ncx * (cell[1][ey] + (long long)P.ncy * cell[2][ez]));
             const double q0 = pc[0], q1 = pc[1], q2 = pc[2], q3 = pc[3];
-            const double Nx0 = P.h[0] * P.N[ax][0], Nx1 = P.h[0] * P.N[ax][1], Ny0 = P.h[1] * P.N[ay][0], Ny1 = P.h[1] * P.N[ay][1],
-                         Nz0 = P.h[2] * P.N[az][0], Nz1 = P.h[2] * P.N[az][1];
+            const double Nx0 = wN0[0][ex], Nx1 = wN1[0][ex], Ny0 = wN0[1][ey], Ny1 = wN1[1][ey], Nz0 = wN0[2][ez], Nz1 = wN1[2][ez];
+            const double Cx0 = wC0[0][ex], Cx1 = wC1[0][ex], Cy0 = wC0[1][ey], Cy1 = wC1[1][ey], Cz0 = wC0[2][ez], Cz1 = wC1[2][ez];
             // int (q0 + q1 l(xi) + q2 l(eta) + q3 l(zeta)) d phi / d x_c
-            g[0] += (q0 * P.C[ax][0] + q1 * P.C[ax][1]) * Ny0 * Nz0 + P.C[ax][0] * (q2 * Ny1 * Nz0 + q3 * Ny0 * Nz1);
-            g[1] += (q0 * P.C[ay][0] + q2 * P.C[ay][1]) * Nx0 * Nz0 + P.C[ay][0] * (q1 * Nx1 * Nz0 + q3 * Nx0 * Nz1);
-            g[2] += (q0 * P.C[az][0] + q3 * P.C[az][1]) * Nx0 * Ny0 + P.C[az][0] * (q1 * Nx1 * Ny0 + q2 * Nx0 * Ny1);
+            g[0] += (q0 * Cx0 + q1 * Cx1) * Ny0 * Nz0 + Cx0 * (q2 * Ny1 * Nz0 + q3 * Ny0 * Nz1);
+            g[1] += (q0 * Cy0 + q2 * Cy1) * Nx0 * Nz0 + Cy0 * (q1 * Nx1 * Nz0 + q3 * Nx0 * Nz1);
+            g[2] += (q0 * Cz0 + q3 * Cz1) * Nx0 * Ny0 + Cz0 * (q1 * Nx1 * Ny0 + q2 * Nx0 * Ny1);
           }
-        }
-      }
 _Pragma("unroll") for (int o = 0; o < NO; ++o)
         if (o < P.nout)
           for (int c = 0; c < 3; ++c) acc[o][c] = fma(P.wKu[o][s], g[c], acc[o][c]);
