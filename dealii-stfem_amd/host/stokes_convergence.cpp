@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 using namespace stfem;
 
@@ -29,6 +30,23 @@ inline double d2A(double s) { return 2 * PI * PI * std::cos(2 * PI * s); }
 inline double B(double s) { return 0.5 * std::sin(2 * PI * s); }
 inline double dB(double s) { return PI * std::cos(2 * PI * s); }
 inline double d2B(double s) { return -4 * PI * PI * B(s); }
+// the analytic functions are evaluated at up to 10^7 points per call (27 quadrature points per cell): the point loop in slices on
+// the host's cores (the reference evaluates its Functions inside the threaded cell loops of deal.II)
+template <typename Body> void for_points(size_t n, Body &&body)
+{
+  const unsigned nthreads = n < 65536 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (nthreads == 1) {
+    body(size_t(0), n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t chunk = (n + nthreads - 1) / nthreads;
+  for (unsigned t = 0; t < nthreads; ++t) {
+    const size_t lo = std::min(n, t * chunk), hi = std::min(n, lo + chunk);
+    if (lo < hi) pool.emplace_back([&body, lo, hi] { body(lo, hi); });
+  }
+  for (auto &th : pool) th.join();
+}
 } // namespace
 
 int main(int argc_all, char **argv_all)
@@ -81,7 +99,8 @@ int main(int argc_all, char **argv_all)
       const size_t np = p.size() / 3;
       const double st = std::sin(t), ct = std::cos(t);
       for (auto &o : out) o.resize(np);
-      for (size_t i = 0; i < np; ++i) {
+      for_points(np, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
         const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
         const double lap1 = d2A(x) * B(y) * A(z) + A(x) * d2B(y) * A(z) + A(x) * B(y) * d2A(z);
         const double lap2 = d2B(x) * A(y) * A(z) + B(x) * d2A(y) * A(z) + B(x) * A(y) * d2A(z);
@@ -90,31 +109,38 @@ int main(int argc_all, char **argv_all)
         out[1][i] = -2 * PI * (ct * B(x) * A(y) * A(z) - nu * st * lap2) - PI * st * cx * sy * cz;
         out[2][i] = -PI * st * cx * cy * sz;
       }
+      });
     };
     auto exact_u = [&](int c) {
       return PointFunction([c](double t, const std::vector<double> &p, std::vector<double> &out) {
         out.resize(p.size() / 3);
         const double a = 2 * PI * std::sin(t);
-        for (size_t i = 0; i < out.size(); ++i) {
-          const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
-          out[i] = c == 0 ? a * A(x) * B(y) * A(z) : (c == 1 ? -a * B(x) * A(y) * A(z) : 0.0);
-        }
+        for_points(out.size(), [&](size_t lo, size_t hi) {
+          for (size_t i = lo; i < hi; ++i) {
+            const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+            out[i] = c == 0 ? a * A(x) * B(y) * A(z) : (c == 1 ? -a * B(x) * A(y) * A(z) : 0.0);
+          }
+        });
       });
     };
     auto exact_grad_u = [&](int c) {
       return PointFunction([c](double t, const std::vector<double> &p, std::vector<double> &out) {
         out.assign(p.size(), 0.0);
         const double a = 2 * PI * std::sin(t);
-        for (size_t i = 0; i < p.size() / 3; ++i) {
-          const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
-          if (c == 0) { out[3 * i] = a * dA(x) * B(y) * A(z); out[3 * i + 1] = a * A(x) * dB(y) * A(z); out[3 * i + 2] = a * A(x) * B(y) * dA(z); }
-          if (c == 1) { out[3 * i] = -a * dB(x) * A(y) * A(z); out[3 * i + 1] = -a * B(x) * dA(y) * A(z); out[3 * i + 2] = -a * B(x) * A(y) * dA(z); }
-        }
+        for_points(p.size() / 3, [&](size_t lo, size_t hi) {
+          for (size_t i = lo; i < hi; ++i) {
+            const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+            if (c == 0) { out[3 * i] = a * dA(x) * B(y) * A(z); out[3 * i + 1] = a * A(x) * dB(y) * A(z); out[3 * i + 2] = a * A(x) * B(y) * dA(z); }
+            if (c == 1) { out[3 * i] = -a * dB(x) * A(y) * A(z); out[3 * i + 1] = -a * B(x) * dA(y) * A(z); out[3 * i + 2] = -a * B(x) * A(y) * dA(z); }
+          }
+        });
       });
     };
     const PointFunction exact_p = [](double t, const std::vector<double> &p, std::vector<double> &out) {
       out.resize(p.size() / 3);
-      for (size_t i = 0; i < out.size(); ++i) out[i] = std::sin(t) * std::cos(PI * p[3 * i]) * std::cos(PI * p[3 * i + 1]) * std::cos(PI * p[3 * i + 2]);
+      for_points(out.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) out[i] = std::sin(t) * std::cos(PI * p[3 * i]) * std::cos(PI * p[3 * i + 1]) * std::cos(PI * p[3 * i + 2]);
+      });
     };
 
     // the preconditioner behind one interface: relaxation sweeps on the finest level, or one V-cycle
