@@ -1416,7 +1416,15 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
   bool any_p = false;
   for (int o = 0; o < nout; ++o) any_p = any_p || prm.out_p[o];
   (void)k_p; // (a destination that is overwritten is written even with zero weights)
-  const bool forked = any_p && !serial && c->side;
+  // Off unless STFEM_STOKES_FORK_MIN_CELLS names the mesh size from which to fork: in a back-to-back sequence of vmults the fork gains
+  // 4 % with the FE_DGP(1) pressure and nothing with FE_Q(1) (the sweep with the gradient folded in leaves no registers for a second
+  // kernel on the CU), but a solver's sequence of forked vmults interleaved with other launches - a V-cycle has ~10^3 per cycle - runs
+  // three times slower than the same sequence on one stream (profiles/r3/experiments.txt Z: 48 -> 16 ms per FGMRES iteration on 64^3 cells)
+  static const long long fork_min_cells = [] {
+    const char *e = getenv("STFEM_STOKES_FORK_MIN_CELLS");
+    return e ? atoll(e) : 0x7fffffffffffffffll;
+  }();
+  const bool forked = any_p && !serial && c->side && (long long)k.ncx * k.ncy * k.ncz >= fork_min_cells;
   static const bool div_gather = [] { const char *e = getenv("STFEM_STOKES_DIV_GATHER"); return e && atoi(e) != 0; }();
   auto launch_div = [&](hipStream_t st) {
     if (k.pdg && shape <= 1 && !div_gather) { // FE_DGP(1), up to two time dofs: one thread per cell

@@ -8,6 +8,8 @@
 #include "time_integrators.h"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace stfem {
 
@@ -265,6 +267,14 @@ public:
   const std::shared_ptr<StokesSpaces> &finest_spaces() const { return levels_.back().spaces; }
   double relaxation(unsigned level) const { return levels_.at(level).omega; }
   unsigned n_levels() const { return unsigned(levels_.size()); }
+  // STFEM_MG_TIMING=1: wall time per level (smoothing, residual + transfers), with a device synchronisation around every section -
+  // the sections of the reference's TimerOutput ("gmg" and below); the synchronisations cost the overlap of launches and kernels
+  void print_timing(FILE *f) const
+  {
+    if (!timing_) return;
+    for (unsigned l = 0; l < levels_.size(); ++l)
+      std::fprintf(f, "level %u: smoothing %.3f s, residual and transfers %.3f s (%u cycles)\n", l, levels_[l].t_smooth, levels_[l].t_transfer, cycles_);
+  }
 
   // PreconditionMG::vmult: copy_to_mg, one V-cycle from zero, copy_from_mg
   void vmult(StokesBlockVector &dst, const StokesBlockVector &src, void * = nullptr) const
@@ -275,6 +285,7 @@ public:
     const unsigned nb = levels_[top].slice.n_blocks();
     for (unsigned b = 0; b < nb; ++b) axpby(1.0, foreign_view(src, b), 0.0, levels_[top].defect.view(b));
     level_v_step(top);
+    ++cycles_;
     for (unsigned b = 0; b < nb; ++b) {
       BlockVectorT<double> d = foreign_view(dst, b);
       axpby(1.0, levels_[top].solution.view(b), 0.0, d);
@@ -298,6 +309,26 @@ private:
     std::unique_ptr<MGTwoLevelTransfer<double>> tr_u, tr_p; // to the level below
     double omega = 1.0;
     mutable StokesBlockVector defect, solution, t, tmp;
+    mutable double t_smooth = 0.0, t_transfer = 0.0;
+  };
+  struct Section { // (times one section of the cycle when STFEM_MG_TIMING is set)
+    Section(bool on, double &acc) : on(on), acc(acc)
+    {
+      if (on) {
+        (void)stfem_stream_synchronize(nullptr);
+        t0 = std::chrono::steady_clock::now();
+      }
+    }
+    ~Section()
+    {
+      if (on) {
+        (void)stfem_stream_synchronize(nullptr);
+        acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
+    }
+    bool on;
+    double &acc;
+    std::chrono::steady_clock::time_point t0;
   };
   void build(const Mesh &mesh, double viscosity, const std::set<boundary_id> &weak_boundary_ids, TimeStepType type)
   {
@@ -397,11 +428,16 @@ private:
   {
     const Level &L = levels_[level];
     if (level == 0) { // MGCoarseGridApplySmoother
+      Section sec(timing_, L.t_smooth);
       smooth(0, true);
       return;
     }
     const Level &C = levels_[level - 1];
-    smooth(level, true);
+    {
+      Section sec(timing_, L.t_smooth);
+      smooth(level, true);
+    }
+    std::unique_ptr<Section> down(new Section(timing_, L.t_transfer));
     L.system->vmult(L.t, L.solution);
     axpby(1.0, L.defect, -1.0, L.t);
     set_zero(C.defect);
@@ -416,7 +452,9 @@ private:
       const MGTwoLevelTransfer<double> &tr = slice.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
       check(stfem_transfer_restrict(tr.handle(), C.defect.view(b).handle(), L.t.view(b).handle(), 1, nullptr), "GMGStokes: restrict_and_add");
     }
+    down.reset();
     level_v_step(level - 1);
+    std::unique_ptr<Section> up(new Section(timing_, L.t_transfer));
     if (in_time) time_transfer(L, L.solution, L.time_prolongation, C, C.solution);
     for (unsigned b = 0; b < slice.n_blocks() && !in_time; ++b) {
       if (slice.decompose(b)[1] == 1 && dg_) {
@@ -427,8 +465,15 @@ private:
       const MGTwoLevelTransfer<double> &tr = slice.decompose(b)[1] == 0 ? *L.tr_u : *L.tr_p;
       check(stfem_transfer_prolongate(tr.handle(), L.solution.view(b).handle(), C.solution.view(b).handle(), 1, nullptr), "GMGStokes: prolongate_and_add");
     }
+    up.reset();
+    Section sec(timing_, L.t_smooth);
     smooth(level, false);
   }
+  bool timing_ = [] {
+    const char *e = std::getenv("STFEM_MG_TIMING");
+    return e && std::atoi(e) != 0;
+  }();
+  mutable unsigned cycles_ = 0;
   AdditionalData data_;
   bool dg_ = false;
   std::vector<Level> levels_;

@@ -219,6 +219,7 @@ int main(int argc_all, char **argv_all)
     }
     std::fprintf(stderr, "%u slab solves: %.3f s (right-hand side on the host + FGMRES), FGMRES alone %.3f s for %u iterations = %.2f ms per iteration\n", solves,
                  solve_seconds, step.solver_seconds(), iterations, 1e3 * step.solver_seconds() / std::max(1u, iterations));
+    if (gmg) gmg->print_timing(stderr);
     std::printf("%d %lld %lld %u %.12e %.12e %.12e %.12e %.2f\n", n * n * n, 3ll * (long long)nu_dofs, (long long)stfem_stokes_n_pressure_dofs(K.handle()), nt, l8,
                 std::sqrt(l2), std::sqrt(h1), std::sqrt(l2p), double(iterations) / solves);
     return 0;

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 stfem = importlib.import_module("dealii-stfem_amd")
 dg = len(sys.argv) > 1 and sys.argv[1] == "dg"
 Alpha, Beta, _, _ = stfem.get_fe_time_weights_stokes(stfem.CGP, 1, 1.0 / 64, 1)
-for N in (2, 4, 8, 16, 32):
+for N in [int(a) for a in sys.argv[2:]] or (2, 4, 8, 16, 32):
     op = stfem.StokesMatrixFreeOperator((N, N, N), viscosity=1.0, dg_pressure=dg)
     rng = np.random.default_rng(0)
     src = [op.initialize_dof_vector(v, rng.uniform(-1, 1, 3 * op.n_velocity if v == 0 else op.n_pressure)) for v in (0, 1)]
