@@ -26,6 +26,7 @@
 #include "stfem_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -1128,6 +1129,20 @@ static int stokes_lowest_priority()
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return lo;
 }
+// One side stream per device for all Stokes contexts (a multigrid has one context per level: a stream each would outnumber the
+// hardware queues, and dependencies between streams that share a queue are resolved on the host).  Never destroyed.
+static hipStream_t stokes_side_stream(int device)
+{
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!streams[device] && hipStreamCreateWithPriority(&streams[device], hipStreamNonBlocking, stokes_lowest_priority()) != hipSuccess) {
+    (void)hipGetLastError();
+    streams[device] = nullptr;
+  }
+  return streams[device];
+}
 #define STOKES_TRY(call)                                                   \
   do {                                                                     \
     hipError_t e_ = (call);                                                \
@@ -1243,11 +1258,9 @@ int stfem_stokes_create_ex(const stfem_mesh_desc *mesh, int velocity_degree, int
       stfem_space_desc sd{2, 3, 1, 0};
       const int rc = stfem_ctx_create(&md, &sd, &c->scalar);
       if (rc != STFEM_OK) c->scalar = nullptr; // (the cell kernel serves then)
-      else if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, stokes_lowest_priority()) != hipSuccess ||
-               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      else if (!(c->side = stokes_side_stream(c->device)) || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
-        if (c->side) (void)hipStreamDestroy(c->side);
         c->side = nullptr; // (the divergence kernel then follows the sweep on the caller's stream)
       }
     }
@@ -1285,7 +1298,6 @@ void stfem_stokes_destroy(stfem_stokes_ctx *c)
   if (c->pressure_space) stfem_ctx_destroy(c->pressure_space);
   if (c->d_pq) (void)hipFree(c->d_pq);
   if (c->d_pred) (void)hipFree(c->d_pred);
-  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
@@ -1416,15 +1428,21 @@ static int stokes_cart_launch(stfem_stokes_ctx *c, const StokesParams &prm, hipS
   bool any_p = false;
   for (int o = 0; o < nout; ++o) any_p = any_p || prm.out_p[o];
   (void)k_p; // (a destination that is overwritten is written even with zero weights)
-  // Off unless STFEM_STOKES_FORK_MIN_CELLS names the mesh size from which to fork: in a back-to-back sequence of vmults the fork gains
-  // 4 % with the FE_DGP(1) pressure and nothing with FE_Q(1) (the sweep with the gradient folded in leaves no registers for a second
-  // kernel on the CU), but a solver's sequence of forked vmults interleaved with other launches - a V-cycle has ~10^3 per cycle - runs
-  // three times slower than the same sequence on one stream (profiles/r3/experiments.txt Z: 48 -> 16 ms per FGMRES iteration on 64^3 cells)
+  // The fork onto the side stream - ONE per device, shared by every Stokes context: with a stream per context (a multigrid has one
+  // context per level) the streams outnumbered the hardware queues, and the multigrid-preconditioned solve ran three times slower
+  // than on one stream (profiles/r3/experiments.txt Z: 64^3 cells, 47 against 16 ms per FGMRES iteration).  No fork where the
+  // gradient term rides in the sweep (FE_Q(1), one time dof): that sweep leaves no registers for a second kernel on the CU.
+  // STFEM_STOKES_FORK_MIN_CELLS=<n>: fork on meshes of at least n cells only (measurements).
   static const long long fork_min_cells = [] {
     const char *e = getenv("STFEM_STOKES_FORK_MIN_CELLS");
-    return e ? atoll(e) : 0x7fffffffffffffffll;
+    return e ? atoll(e) : 0ll;
   }();
-  const bool forked = any_p && !serial && c->side && (long long)k.ncx * k.ncy * k.ncz >= fork_min_cells;
+  static const bool unfused_grad = [] { const char *e = getenv("STFEM_STOKES_GRAD_KERNEL"); return e && atoi(e) != 0; }();
+  int n_store_u = 0, n_add_u = 0;
+  for (int o = 0; o < nout; ++o)
+    if (prm.out_u[o]) (prm.store_u[o] ? n_store_u : n_add_u)++;
+  const bool gradient_in_sweep = nsrc == 1 && n_store_u == 1 && n_add_u == 0 && !c->pspace && ps[0] && k_u && !unfused_grad;
+  const bool forked = any_p && !serial && c->side && !gradient_in_sweep && (long long)k.ncx * k.ncy * k.ncz >= fork_min_cells;
   static const bool div_gather = [] { const char *e = getenv("STFEM_STOKES_DIV_GATHER"); return e && atoi(e) != 0; }();
   auto launch_div = [&](hipStream_t st) {
     if (k.pdg && shape <= 1 && !div_gather) { // FE_DGP(1), up to two time dofs: one thread per cell
