@@ -108,6 +108,7 @@ SIGNATURES = {
     "stfem_integrate_difference_product": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _dp, _vp]),
     "stfem_vector_axpby": (C.c_int, [_vp, C.c_double, _vp, C.c_double, _vp, _vp]),
     "stfem_vector_set_zero": (C.c_int, [_vp, _vp, _vp]),
+    "stfem_axpby_many": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.c_double, C.POINTER(_vp), C.c_double, C.POINTER(_vp), _vp]),
     "stfem_driver_last_error": (C.c_char_p, []),
     "stfem_gauss_rule": (C.c_int, [C.c_int, _dp, _dp]),
     "stfem_fe_time_points": (C.c_int, [C.c_int, C.c_int, _dp]),
@@ -844,3 +845,18 @@ class StokesVector:
         if getattr(self, "ptr", None) and _lib is not None and getattr(self.op, "_h", None):
             _lib.stfem_stokes_vector_destroy(self.op._h, self.ptr)
             self.ptr = None
+
+
+def axpby_many(ctx, a, xs, b, ys, stream=None):
+    """y_i = a x_i + b y_i on device arrays of different lengths in one launch (stfem_axpby_many); xs / ys: objects with .ptr and
+    .size (StokesVector) or (pointer, length) pairs"""
+    def pl(v):
+        return (v.ptr, v.size) if hasattr(v, "ptr") else (int(v[0]), int(v[1]))
+    n = len(ys)
+    py = [pl(v) for v in ys]
+    px = [pl(v) for v in xs] if xs is not None else [(None, ln) for _, ln in py]
+    assert len(px) == n and all(a_[1] == b_[1] for a_, b_ in zip(px, py))
+    lens = (C.c_int64 * n)(*[ln for _, ln in py])
+    X = (_vp * n)(*[p for p, _ in px])
+    Y = (_vp * n)(*[p for p, _ in py])
+    _check(lib().stfem_axpby_many(ctx._h, n, lens, float(a), X, float(b), Y, stream), "stfem_axpby_many")

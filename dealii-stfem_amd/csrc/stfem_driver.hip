@@ -262,6 +262,29 @@ __global__ __launch_bounds__(256) void axpby_kernel(int64_t n, T a, T b, const A
     for (int64_t i = i0; i < n; i += stride) y[i] = a * x[i] + b * y[i];
 }
 
+// the same on arrays of different lengths in one launch (the blocks of a two-variable vector: velocity and pressure blocks)
+struct AxpbyMany {
+  const void *x[8];
+  void *y[8];
+  long long len[8];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_many_kernel(T a, T b, const AxpbyMany v)
+{
+  const T *x = static_cast<const T *>(v.x[blockIdx.y]);
+  T *y = static_cast<T *>(v.y[blockIdx.y]);
+  const int64_t n = v.len[blockIdx.y];
+  const int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+  if (a == T(0) && b == T(0))
+    for (int64_t i = i0; i < n; i += stride) y[i] = T(0);
+  else if (a == T(0))
+    for (int64_t i = i0; i < n; i += stride) y[i] = b * y[i];
+  else if (b == T(0))
+    for (int64_t i = i0; i < n; i += stride) y[i] = a * x[i];
+  else
+    for (int64_t i = i0; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+}
+
 // device copies of the geometry and of the tables of QGauss(nq) against the context's nodal basis
 struct GeomUpload {
   double *d = nullptr;
@@ -479,6 +502,32 @@ int stfem_vector_axpby(stfem_ctx *c, double a, const stfem_vec *x, double b, stf
     }
     if (c->prec) hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid, nb), dim3(256), 0, st, c->ndofs, float(a), float(b), bl);
     else hipLaunchKernelGGL(axpby_kernel<double>, dim3(grid, nb), dim3(256), 0, st, c->ndofs, a, b, bl);
+  }
+  return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
+}
+
+int stfem_axpby_many(stfem_ctx *c, int n_arrays, const int64_t *len, double a, const void *const *x, double b, void *const *y, void *stream)
+{
+  if (!c || n_arrays < 0 || (n_arrays > 0 && (!len || !y || (a != 0.0 && !x)))) return STFEM_ERR_INVALID_ARGUMENT;
+  for (int j = 0; j < n_arrays; ++j)
+    if (len[j] < 0 || !y[j] || (a != 0.0 && !x[j])) return STFEM_ERR_INVALID_ARGUMENT;
+  DRV_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
+  for (int b0 = 0; b0 < n_arrays; b0 += 8) {
+    const int nb = std::min(8, n_arrays - b0);
+    AxpbyMany v{};
+    long long longest = 0;
+    for (int j = 0; j < nb; ++j) {
+      v.x[j] = a != 0.0 ? x[b0 + j] : nullptr;
+      v.y[j] = y[b0 + j];
+      v.len[j] = len[b0 + j];
+      longest = std::max<long long>(longest, len[b0 + j]);
+    }
+    if (longest == 0) continue;
+    const unsigned grid = (unsigned)std::min<long long>((longest + 255) / 256, 4096);
+    if (c->prec) hipLaunchKernelGGL(axpby_many_kernel<float>, dim3(grid, nb), dim3(256), 0, st, float(a), float(b), v);
+    else hipLaunchKernelGGL(axpby_many_kernel<double>, dim3(grid, nb), dim3(256), 0, st, a, b, v);
   }
   return hipGetLastError() == hipSuccess ? STFEM_OK : STFEM_ERR_HIP;
 }

@@ -89,14 +89,22 @@ inline void reinit_like(StokesBlockVector &v, const StokesBlockVector &x)
 {
   if (v.empty()) v.reinit(x.spaces(), x.stokes(), x.slice());
 }
+// all blocks in one launch (stfem_axpby_many: the blocks of the two variables differ in length)
 inline void axpby(double a, const StokesBlockVector &x, double b, StokesBlockVector &y, void *stream = nullptr)
 {
-  for (unsigned i = 0; i < y.n_blocks(); ++i) axpby(a, x.view(i), b, y.view(i), stream);
+  const unsigned nb = y.n_blocks();
+  std::vector<int64_t> len(nb);
+  std::vector<const void *> px(nb);
+  std::vector<void *> py(nb);
+  for (unsigned i = 0; i < nb; ++i) {
+    if (x.blocks()[i].size() != y.blocks()[i].size()) throw Error(STFEM_ERR_SHAPE_MISMATCH, "axpby: block sizes");
+    len[i] = int64_t(y.blocks()[i].size());
+    px[i] = x.blocks()[i].data();
+    py[i] = y.blocks()[i].data();
+  }
+  check(stfem_axpby_many(y.spaces()->q2->h, int(nb), len.data(), a, px.data(), b, py.data(), stream), "stfem_axpby_many");
 }
-inline void set_zero(StokesBlockVector &v, void *stream = nullptr)
-{
-  for (unsigned i = 0; i < v.n_blocks(); ++i) set_zero(v.view(i), stream);
-}
+inline void set_zero(StokesBlockVector &v, void *stream = nullptr) { axpby(0.0, v, 0.0, v, stream); }
 inline double dot(const StokesBlockVector &a, const StokesBlockVector &b)
 {
   double s = 0.0;

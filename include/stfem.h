@@ -349,6 +349,10 @@ int stfem_integrate_difference_product(stfem_ctx *ctx, int nq, const stfem_vec *
                                        void *stream);
 int stfem_vector_axpby(stfem_ctx *ctx, double a, const stfem_vec *x, double b, stfem_vec *y, void *stream);
 int stfem_vector_set_zero(stfem_ctx *ctx, stfem_vec *y, void *stream);
+/* the same arithmetic on n_arrays device arrays of len[i] elements of the context's Number in ONE launch: y_i = a x_i + b y_i with the
+ * zero-factor rules of stfem_vector_axpby (x may be NULL when a = 0).  For vectors whose blocks differ in length - the velocity and
+ * pressure blocks of the Stokes system (BlockVectorT::sadd / equ / = 0 over all blocks of a two-variable vector) */
+int stfem_axpby_many(stfem_ctx *ctx, int n_arrays, const int64_t *len, double a, const void *const *x, double b, void *const *y, void *stream);
 const char *stfem_driver_last_error(void);
 /* QGauss(n) on [0, 1]; the support points of the temporal basis, get_time_quad (fe_time.cc:152-161): QGaussLobatto(r + 1)
  * for cG(r) (type 0), QGaussRadau(r + 1, right) for dG(r) (type 1); r + 1 values */

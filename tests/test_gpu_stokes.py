@@ -390,3 +390,30 @@ def test_stokes_on_z_slabs_equals_whole_mesh(world, dg, r, stfem):
         for z0, z1, out, _ in parts:
             total[:, step * z0:step * z1 + 1] += out[b].reshape(comps, step * (z1 - z0) + 1, plane)
         assert rel(total.reshape(-1), want[b]) < TOL, b
+
+
+def test_axpby_on_the_blocks_of_a_two_variable_vector(stfem):
+    """stfem_axpby_many: the vector arithmetic of the Krylov solver and the multigrid on velocity and pressure blocks in one launch,
+    with the zero-factor rules of stfem_vector_axpby (a zero factor means "not read": NaN does not survive an assignment)"""
+    op = stfem.StokesMatrixFreeOperator((5, 4, 3))
+    ctx = stfem.MatrixFreeOperator(2, (5, 4, 3))  # (any context of the device and precision)
+    rng = np.random.default_rng(3)
+    X = [rng.uniform(-1, 1, 3 * op.n_velocity), rng.uniform(-1, 1, op.n_pressure), rng.uniform(-1, 1, 3 * op.n_velocity)]
+    Y = [rng.uniform(-1, 1, v.size) for v in X]
+    var = [0, 1, 0]
+    x = [op.initialize_dof_vector(v, h) for v, h in zip(var, X)]
+    y = [op.initialize_dof_vector(v, h) for v, h in zip(var, Y)]
+    stfem.axpby_many(ctx, 0.5, x, -2.0, y)
+    for yv, xh, yh in zip(y, X, Y):
+        assert np.array_equal(yv.download(), 0.5 * xh + -2.0 * yh)
+    nan = [op.initialize_dof_vector(v, np.full(h.size, np.nan)) for v, h in zip(var, X)]
+    stfem.axpby_many(ctx, 3.0, x, 0.0, nan)          # equ: the old content (NaN) is not read
+    for nv, xh in zip(nan, X):
+        assert np.array_equal(nv.download(), 3.0 * xh)
+    bad = [op.initialize_dof_vector(v, np.full(h.size, np.inf)) for v, h in zip(var, X)]
+    stfem.axpby_many(ctx, 0.0, bad, 0.0, bad)        # = 0
+    for bv in bad:
+        assert np.all(bv.download() == 0.0)
+    stfem.axpby_many(ctx, 0.0, None, 2.0, y)         # scaling: x is not needed
+    for yv, xh, yh in zip(y, X, Y):
+        assert np.allclose(yv.download(), 2.0 * (0.5 * xh - 2.0 * yh), rtol=1e-15, atol=0)
